@@ -1,0 +1,175 @@
+/* ssrs_hip.h -- C ABI of libssrs_hip.so, the MI355X (gfx950) implementation of
+ * the SSRS data-parallel hot path: the updraft raster and the stochastic track
+ * stepper.
+ *
+ * SSRS has no FFI/plugin seam of its own: the boundary this library replaces
+ * is the set of module-level numeric functions that ssrs/simulator.py imports
+ * by name (/root/reference/ssrs/simulator.py:21-28).  Each entry point below
+ * cites the reference function it stands in for; INTEGRATION.md shows the
+ * ctypes stub a maintainer of the reference would add at each call site.
+ *
+ * Conventions
+ *  - every array pointer is CALLER-OWNED DEVICE memory (e.g. a torch tensor's
+ *    data_ptr()), row-major (rows, cols), row 0 = south, unless marked [host];
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *  - raster entry points are asynchronous on `stream`; ssrs_tracks_simulate
+ *    drives a launch loop and returns after the last launch has completed;
+ *  - return value: SSRS_OK (0) or a negative SSRS_ERR_* code, with a
+ *    thread-local message available from ssrs_last_error();
+ *  - no hidden global state: the random stream is a pure function of
+ *    (seed, global track id, step) -- see "Uniform contract" below;
+ *  - thread-safe for distinct streams / devices.
+ *
+ * Uniform contract (replaces the reference's serial global MT19937 draw in
+ * np.random.choice, movmodel.py:312, which no parallel run can reproduce):
+ *   u(seed, track, step) = ((a >> 5) * 2^26 + (b >> 6)) / 2^53,
+ *   (a, b) = words (0,1) [even step] or (2,3) [odd step] of
+ *   Philox4x32-10(key = {seed lo, seed hi},
+ *                 ctr = {blk lo, blk hi, track lo, track hi}),  blk = step >> 1,
+ * i.e. exactly rocRAND's rocrand_init(seed, track, 2*step) + 2 x rocrand().
+ */
+#ifndef SSRS_HIP_H_
+#define SSRS_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSRS_VERSION 100 /* 0.1.0 */
+
+#define SSRS_OK 0
+#define SSRS_ERR_INVALID (-1) /* bad argument (message says which) */
+#define SSRS_ERR_HIP (-2)     /* a HIP runtime call failed */
+#define SSRS_ERR_START (-3)   /* a start cell lies outside the raster */
+
+/* element type selectors for `const void*` rasters */
+#define SSRS_F32 0
+#define SSRS_F64 1
+
+int ssrs_version(void);
+const char *ssrs_last_error(void);
+/* name[] receives the device name; returns SSRS_OK or SSRS_ERR_HIP */
+int ssrs_device_info(int device, char *name, size_t name_len, int *compute_units,
+                     size_t *hbm_bytes);
+
+/* ------------------------------------------------------------------ raster */
+
+/* compute_slope_degrees + compute_aspect_degrees (ssrs/layers.py:63-128):
+ * Horn 3x3 gradients on the DEM, slope = deg(atan|grad|), aspect per :124-127,
+ * border cells 0.  slope or aspect may be NULL.  f64 arithmetic. */
+int ssrs_slope_aspect(const void *dem, int dem_type, double res, void *slope,
+                      void *aspect, int out_type, int rows, int cols, void *stream);
+
+/* compute_orographic_updraft (ssrs/layers.py:11-22) for `batch` wind cases over
+ * one terrain, optionally fused with get_above_threshold_speed
+ * (ssrs/layers.py:171-185, applied to the f32-rounded orograph exactly as
+ * Simulator.load_updrafts does after np.save(float32), simulator.py:198,233-242).
+ *   slope, aspect   (rows, cols) of in_type
+ *   wspeed, wdirn   NULL -> uniform mode, wspeed0[b] / wdirn0[b] ([host], length
+ *                   batch); else (batch, rows, cols) rasters of wind_type
+ *   orograph        (batch, rows, cols) f32 out, may be NULL
+ *   threshold       < 0 -> `usable` is not written
+ *   usable          (batch, rows, cols) f64 out (thresholded updraft), may be NULL */
+int ssrs_orographic_updraft(const void *slope, const void *aspect, int in_type,
+                            const void *wspeed, const void *wdirn, int wind_type,
+                            const double *wspeed0, const double *wdirn0,
+                            double min_updraft_val, float *orograph,
+                            double threshold, double *usable, int rows, int cols,
+                            int batch, void *stream);
+
+/* get_above_threshold_speed (ssrs/layers.py:171-185) on n f32 values -> f64. */
+int ssrs_threshold_updraft(const float *in, double threshold, double *out,
+                           size_t n, void *stream);
+
+/* Fused DEM -> orographic updraft (-> usable updraft): slope/aspect/orographic/
+ * threshold of layers.py:11-22,63-128,171-185 in one pass over an LDS-staged
+ * DEM tile, uniform wind.  Trig-free: sin(slope) cos(aspect - wdirn) is
+ * evaluated from the Horn gradients directly (DESIGN.md "K1"); results agree
+ * with the reference expression to a few f64 ulps before the f32 rounding.
+ * orograph / usable as above (batch = 1). */
+int ssrs_updraft_from_dem(const void *dem, int dem_type, double res, double wspeed,
+                          double wdirn, double min_updraft_val, float *orograph,
+                          double threshold, double *usable, int rows, int cols,
+                          void *stream);
+
+/* ----------------------------------------------------------------- stepper */
+
+/* Per-run constants of generate_simulated_tracks (ssrs/movmodel.py:264-318).
+ * Fill with ssrs_track_params_init() or by hand. */
+typedef struct SsrsTrackParams {
+    int32_t rows, cols;
+    int32_t burnin;           /* int(min(rows, cols) / 10), movmodel.py:276 */
+    int32_t memory_parameter; /* directions[-m:], 0..8 (0 = whole history) */
+    int64_t max_moves;        /* ceil(rows / 2 * cols / 2), movmodel.py:277 */
+    double scaling_parameter; /* nu; exact parity is claimed for nu == 1 */
+    double prior[9];          /* get_directional_probs(move_dirn * pi / 180),
+                                 movmodel.py:247-257, computed by the host */
+    int32_t steps_per_launch; /* 0 = default (256) */
+    int32_t flags;            /* SSRS_TRACKS_* */
+} SsrsTrackParams;
+
+#define SSRS_TRACKS_PROFILE 1 /* time every launch with HIP events (stats) */
+
+typedef struct SsrsTrackStats {
+    int64_t total_steps; /* moves taken by all tracks of this call */
+    int32_t launches;    /* stepper kernel launches */
+    float kernel_ms;     /* sum of launch durations (SSRS_TRACKS_PROFILE) */
+    float wall_ms;       /* first launch -> last completion, HIP events */
+} SsrsTrackStats;
+
+/* Fills rows/cols/burnin/max_moves/memory/nu and zeroes the rest; `prior` must
+ * still be supplied by the caller (it needs the host libm/numpy cos). */
+int ssrs_track_params_init(SsrsTrackParams *p, int rows, int cols,
+                           int memory_parameter, double scaling_parameter);
+
+/* Per-cell move weights of movmodel.py:292-306 for every interior cell:
+ *   w_k = hm(max(u_c,1e-6), max(u_k,1e-6)) * f64(f32(phi_c - phi_k) * ninv_k),
+ * clipped at 0 (:231), the 8 neighbours k = 0,1,2,3,5,6,7,8 of one cell stored
+ * as 8 consecutive f64 (64 B, one aligned fetch per step).  A cell with any NaN
+ * weight stores NaN in all 8 (the stepper then takes the :228-230 fallback).
+ * potential may be NULL (updraft-only weights).  table: rows*cols*8 f64. */
+int ssrs_transition_table_build(const double *updraft, const float *potential,
+                                double *table, int rows, int cols, void *stream);
+
+/* Bytes of device scratch ssrs_tracks_simulate needs for `ntracks`. */
+size_t ssrs_tracks_workspace_bytes(int64_t ntracks);
+
+/* generate_simulated_tracks for a batch of tracks (movmodel.py:264-318, driven
+ * as Simulator.simulate_tracks does, simulator.py:360-369) + the histogram of
+ * compute_presence_counts (movmodel.py:410-419).
+ *   updraft    f64 (rows, cols) or NULL;  potential f32 (rows, cols) or NULL
+ *              (both NULL = 'drw' mode, simulator.py:370-381)
+ *   table      from ssrs_transition_table_build, or NULL to gather the 3x3
+ *              windows of updraft/potential directly; when given, updraft and
+ *              potential are not read
+ *   start_rc   int32 (ntracks, 2) [row, col]
+ *   seed       sim_seed + real_id (simulator.py:352); track_id_base = global id
+ *              of track 0 of this call (multi-GPU shards pass their offset)
+ *   hist       uint32 (rows, cols), ACCUMULATED (+1 per trajectory point), or NULL
+ *   end_rc     int16 (ntracks, 2) last point, or NULL
+ *   lengths    int32 (ntracks) number of trajectory points, or NULL
+ *   traj       int16 pairs, track t at traj[2*traj_offsets[t] ...], or NULL
+ *   workspace  device scratch of ssrs_tracks_workspace_bytes(ntracks)
+ *   stats      [host] out, may be NULL */
+int ssrs_tracks_simulate(const SsrsTrackParams *params, const double *updraft,
+                         const float *potential, const double *table,
+                         const int32_t *start_rc, int64_t ntracks, uint64_t seed,
+                         uint64_t track_id_base, uint32_t *hist, int16_t *end_rc,
+                         int32_t *lengths, int16_t *traj,
+                         const int64_t *traj_offsets, void *workspace,
+                         size_t workspace_bytes, SsrsTrackStats *stats,
+                         void *stream);
+
+/* n uniforms of the contract above: out[i] = u(seed, track[i], step[i]).
+ * Device self-check of the rocRAND-backed draw used by the stepper. */
+int ssrs_uniform_selftest(uint64_t seed, const uint64_t *track,
+                          const uint64_t *step, double *out, size_t n,
+                          void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSRS_HIP_H_ */

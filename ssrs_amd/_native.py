@@ -1,0 +1,84 @@
+"""ctypes binding of libssrs_hip.so (include/ssrs_hip.h).
+
+There is NO CPU fallback: if the library is missing or a call fails, the
+functions raise.  The library is built in-tree by ssrs_amd/csrc/build.py
+(hipcc, gfx950) and travels with the source tree.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libssrs_hip.so')
+
+SSRS_F32, SSRS_F64 = 0, 1
+SSRS_OK, SSRS_ERR_INVALID, SSRS_ERR_HIP, SSRS_ERR_START = 0, -1, -2, -3
+SSRS_TRACKS_PROFILE = 1
+
+EXPORTS = (
+    'ssrs_version', 'ssrs_last_error', 'ssrs_device_info', 'ssrs_slope_aspect',
+    'ssrs_orographic_updraft', 'ssrs_threshold_updraft', 'ssrs_updraft_from_dem',
+    'ssrs_track_params_init', 'ssrs_transition_table_build',
+    'ssrs_tracks_workspace_bytes', 'ssrs_tracks_simulate', 'ssrs_uniform_selftest',
+)
+
+
+class SsrsTrackParams(C.Structure):
+    _fields_ = [('rows', C.c_int32), ('cols', C.c_int32), ('burnin', C.c_int32),
+                ('memory_parameter', C.c_int32), ('max_moves', C.c_int64),
+                ('scaling_parameter', C.c_double), ('prior', C.c_double * 9),
+                ('steps_per_launch', C.c_int32), ('flags', C.c_int32)]
+
+
+class SsrsTrackStats(C.Structure):
+    _fields_ = [('total_steps', C.c_int64), ('launches', C.c_int32),
+                ('kernel_ms', C.c_float), ('wall_ms', C.c_float)]
+
+
+class SsrsSolveStats(C.Structure):
+    _fields_ = [('iterations', C.c_int32), ('converged', C.c_int32),
+                ('residual', C.c_double), ('kernel_ms', C.c_float)]
+
+
+class SsrsError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f'libssrs_hip error {code}: {message}')
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load libssrs_hip.so once; raise loudly when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f'{LIB_PATH} is missing: build it with `python ssrs_amd/csrc/build.py` '
+                '(hipcc, gfx950). ssrs_amd has no CPU fallback.')
+        L = C.CDLL(LIB_PATH)
+        L.ssrs_version.restype = C.c_int
+        L.ssrs_last_error.restype = C.c_char_p
+        L.ssrs_tracks_workspace_bytes.restype = C.c_size_t
+        L.ssrs_tracks_workspace_bytes.argtypes = [C.c_int64]
+        if hasattr(L, 'ssrs_presence_workspace_bytes'):
+            L.ssrs_presence_workspace_bytes.restype = C.c_size_t
+            L.ssrs_presence_workspace_bytes.argtypes = [C.c_int, C.c_int]
+        if hasattr(L, 'ssrs_potential_workspace_bytes'):
+            L.ssrs_potential_workspace_bytes.restype = C.c_size_t
+            L.ssrs_potential_workspace_bytes.argtypes = [C.c_int, C.c_int]
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != SSRS_OK:
+        msg = lib().ssrs_last_error().decode('utf-8', 'replace')
+        if rc == SSRS_ERR_INVALID or rc == SSRS_ERR_START:
+            raise ValueError(f'libssrs_hip: {msg}')
+        raise SsrsError(rc, msg)
+
+
+def ptr(t):
+    """void* of a torch tensor (None -> NULL)."""
+    return C.c_void_p(0 if t is None else t.data_ptr())

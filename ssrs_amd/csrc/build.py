@@ -1,0 +1,50 @@
+"""Builds ssrs_amd/libssrs_hip.so for gfx950 with hipcc (cross-compiles without
+a GPU).  -ffp-contract=off is REQUIRED: the stepper's move decision reproduces
+the reference's f64 rounding sequence, which a fused multiply-add would break."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+SOURCES = ['capi.hip', 'raster.hip', 'tracks.hip', 'presence.hip', 'potential.hip']
+LIB = os.path.join(PKG, 'libssrs_hip.so')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
+         '-fno-fast-math', '-fgpu-rdc=0' if False else '-Wall', '-Wno-unused-function']
+
+
+def _newest(paths):
+    return max(os.path.getmtime(p) for p in paths)
+
+
+def build(force=False, verbose=False):
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    srcs = [os.path.join(HERE, s) for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
+    deps = srcs + [os.path.join(HERE, 'common.h'),
+                   os.path.join(os.path.dirname(PKG), 'include', 'ssrs_hip.h')]
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest(deps):
+        return LIB
+    objs = []
+    procs = []
+    for s in srcs:
+        o = os.path.splitext(s)[0] + '.o'
+        objs.append(o)
+        if not force and os.path.exists(o) and os.path.getmtime(o) >= _newest(
+                [s, deps[-1], deps[-2]]):
+            continue
+        cmd = [hipcc] + FLAGS + ['-c', s, '-o', o]
+        if verbose:
+            print(' '.join(cmd))
+        procs.append((s, subprocess.Popen(cmd)))
+    for s, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f'hipcc failed on {s}')
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

@@ -1,0 +1,409 @@
+// K1 -- updraft raster kernels for gfx950 (MI355X).
+//
+// Reference semantics (paths relative to /root/reference):
+//   ssrs/layers.py:11-22    compute_orographic_updraft
+//   ssrs/layers.py:63-128   compute_slope_degrees / compute_aspect_degrees
+//   ssrs/layers.py:171-185  get_above_threshold_speed
+//   ssrs/simulator.py:189-243  orographic -> np.save(f32) -> load -> threshold
+//
+// All arithmetic is f64 like the reference; the kernels are HBM-streaming:
+//   k_orographic       12 B/cell (f32 slope+aspect in, f32 out), +8 B if the
+//                      thresholded f64 raster is also written; batched over B
+//                      wind cases so the terrain is read once ((8+12B)/B B)
+//   k_updraft_from_dem 8..12 B/cell: DEM tile (+1-cell halo) staged in LDS,
+//                      Horn gradients -> updraft with no trig at all
+// Built with -ffp-contract=off (see build.py).
+#include "common.h"
+
+namespace ssrs {
+
+constexpr double kPi = 3.141592653589793;  // np.pi
+
+// ----------------------------------------------------------------------------
+// XCD-aware tile order: blocks are dealt round-robin over the 8 XCDs, so give
+// block b the tile (b % 8) * ceil(n/8) + b / 8 (bijective form): each XCD then
+// walks one contiguous band of tiles and finds its halo rows in its own L2.
+__device__ __forceinline__ int xcd_tile(int b, int n)
+{
+    const int q = n / 8, r = n % 8, x = b % 8, j = b / 8;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
+// layers.py:171-185 on one value already rounded to f32 and widened again
+__device__ __forceinline__ double usable_updraft(double v, double thr, double em1)
+{
+    double f = 0.0;
+    if (v > 1e-02) {
+        if (v > thr) {
+            f = v;
+        } else {
+            const double y = v / thr;
+            const double y2 = y * y;
+            const double y5 = (y2 * y2) * y;       // (v/thr)**5
+            f = thr * (exp(y5) - 1.0) / em1;       // em1 = e - 1 (host libm)
+        }
+    }
+    return f;
+}
+
+// ---------------------------------------------------------------------------
+// DEM tile staging: TW x TH outputs per block, (TW+2) x (TH+2) f64 in LDS.
+constexpr int TW = 64;          // one wave spans a tile row: 512 B coalesced
+constexpr int TH = 32;
+constexpr int LW = TW + 2;
+constexpr int LH = TH + 2;
+
+template <typename T>
+__device__ __forceinline__ void stage_dem_tile(const T *__restrict__ dem, int rows,
+                                               int cols, int r0, int c0,
+                                               double *__restrict__ tile)
+{
+    for (int i = threadIdx.x; i < LW * LH; i += kBlock) {
+        const int lr = i / LW, lc = i - lr * LW;
+        int gr = r0 - 1 + lr, gc = c0 - 1 + lc;
+        gr = gr < 0 ? 0 : (gr >= rows ? rows - 1 : gr);   // clamped cells are only
+        gc = gc < 0 ? 0 : (gc >= cols ? cols - 1 : gc);   // read by border outputs
+        tile[i] = static_cast<double>(dem[static_cast<size_t>(gr) * cols + gc]);
+    }
+    __syncthreads();
+}
+
+// Horn gradients exactly in the reference's operand order (layers.py:78-90);
+// "x" is the ROW axis and "y" the COLUMN axis there.
+__device__ __forceinline__ void horn(const double *__restrict__ t, int lr, int lc,
+                                     double res, double &dzdx, double &dzdy)
+{
+    const double *m = t + (lr - 1) * LW + lc;
+    const double *z = t + lr * LW + lc;
+    const double *p = t + (lr + 1) * LW + lc;
+    const double z1 = m[1], z2 = z[1], z3 = p[1];
+    const double z4 = m[0], z6 = p[0];
+    const double z7 = m[-1], z8 = z[-1], z9 = p[-1];
+    const double d = 8 * res;
+    dzdx = ((z3 + 2 * z6 + z9) - (z1 + 2 * z4 + z7)) / d;
+    dzdy = ((z1 + 2 * z2 + z3) - (z7 + 2 * z8 + z9)) / d;
+}
+
+template <typename Tin, typename Tout>
+__global__ __launch_bounds__(kBlock) void k_slope_aspect(
+    const Tin *__restrict__ dem, double res, Tout *__restrict__ slope,
+    Tout *__restrict__ aspect, int rows, int cols, int tiles_x, int ntiles)
+{
+    __shared__ double tile[LW * LH];
+    const int t = xcd_tile(blockIdx.x, ntiles);
+    const int r0 = (t / tiles_x) * TH, c0 = (t % tiles_x) * TW;
+    stage_dem_tile(dem, rows, cols, r0, c0, tile);
+    const int lc = threadIdx.x % TW + 1;
+    const int c = c0 + lc - 1;
+    if (c >= cols) return;
+    const double r2d = 180.0 / kPi;
+    for (int lr = threadIdx.x / TW + 1; lr <= TH; lr += kBlock / TW) {
+        const int r = r0 + lr - 1;
+        if (r >= rows) break;
+        double s = 0.0, a = 0.0;
+        if (r > 0 && c > 0 && r < rows - 1 && c < cols - 1) {
+            double dzdx, dzdy;
+            horn(tile, lr, lc, res, dzdx, dzdy);
+            s = atan(sqrt(dzdx * dzdx + dzdy * dzdy)) * r2d;   // np.degrees
+            const double dx = dzdx == 0.0 ? 1e-10 : dzdx;
+            const double ang = atan(dzdy / dx) * r2d;
+            a = 180.0 - ang + 90.0 * (dx / fabs(dx));
+        }
+        const size_t i = static_cast<size_t>(r) * cols + c;
+        if (slope) slope[i] = static_cast<Tout>(s);
+        if (aspect) aspect[i] = static_cast<Tout>(a);
+    }
+}
+
+template <typename Tin>
+__global__ __launch_bounds__(kBlock) void k_updraft_from_dem(
+    const Tin *__restrict__ dem, double res, double wspeed, double cos_w, double sin_w,
+    double min_val, float *__restrict__ orograph, double thr, double em1,
+    double *__restrict__ usable, int rows, int cols, int tiles_x, int ntiles)
+{
+    __shared__ double tile[LW * LH];
+    const int t = xcd_tile(blockIdx.x, ntiles);
+    const int r0 = (t / tiles_x) * TH, c0 = (t % tiles_x) * TW;
+    stage_dem_tile(dem, rows, cols, r0, c0, tile);
+    const int lc = threadIdx.x % TW + 1;
+    const int c = c0 + lc - 1;
+    if (c >= cols) return;
+    for (int lr = threadIdx.x / TW + 1; lr <= TH; lr += kBlock / TW) {
+        const int r = r0 + lr - 1;
+        if (r >= rows) break;
+        double w = 0.0;
+        if (r > 0 && c > 0 && r < rows - 1 && c < cols - 1) {
+            double dzdx, dzdy;
+            horn(tile, lr, lc, res, dzdx, dzdy);
+            // sin(slope) = g / sqrt(1 + g^2), g = |grad|      (slope = atan g)
+            // cos(aspect - wdirn) = -(dzdy cos w + dx sin w) / g'
+            //   with dx = dzdx (1e-10 when exactly 0, layers.py:124) and
+            //   g' = sqrt(dx^2 + dzdy^2); identity from aspect = 180 - atan(dzdy/dx)
+            //   + 90 sign(dx).
+            const double g2 = dzdx * dzdx + dzdy * dzdy;
+            const double dx = dzdx == 0.0 ? 1e-10 : dzdx;
+            const double proj = -(dzdy * cos_w + dx * sin_w);
+            if (proj > 0.0 && g2 > 0.0) {
+                const double gp2 = dx * dx + dzdy * dzdy;
+                w = wspeed * (proj * sqrt(g2 / (gp2 * (1.0 + g2))));
+            }
+        }
+        w = w > min_val ? w : min_val;
+        const size_t i = static_cast<size_t>(r) * cols + c;
+        const float w32 = static_cast<float>(w);
+        if (orograph) orograph[i] = w32;
+        if (usable) usable[i] = usable_updraft(static_cast<double>(w32), thr, em1);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Elementwise orographic updraft, VEC consecutive cells per thread (16-byte
+// accesses for f32 rasters), batched over wind cases.
+constexpr int kMaxUniformBatch = 16;
+struct UniformWind {
+    double wspeed[kMaxUniformBatch];
+    double wdirn[kMaxUniformBatch];
+};
+
+template <typename T, int VEC>
+struct alignas(sizeof(T) * VEC) Pack {
+    T v[VEC];
+};
+
+template <typename Tin, typename Tw, bool UNIFORM, int VEC>
+__global__ __launch_bounds__(kBlock) void k_orographic(
+    const Tin *__restrict__ slope, const Tin *__restrict__ aspect,
+    const Tw *__restrict__ wspeed, const Tw *__restrict__ wdirn, UniformWind uni,
+    double min_val, float *__restrict__ orograph, double thr, double em1,
+    double *__restrict__ usable, size_t ncells, int batch)
+{
+    const size_t nvec = ncells / VEC;   // host guarantees ncells % VEC == 0
+    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < nvec;
+         i += static_cast<size_t>(gridDim.x) * kBlock) {
+        const Pack<Tin, VEC> s = reinterpret_cast<const Pack<Tin, VEC> *>(slope)[i];
+        const Pack<Tin, VEC> a = reinterpret_cast<const Pack<Tin, VEC> *>(aspect)[i];
+        double sin_s[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+            sin_s[j] = sin(static_cast<double>(s.v[j]) * kPi / 180.0);
+        for (int b = 0; b < batch; ++b) {
+            const size_t o = static_cast<size_t>(b) * nvec + i;
+            Pack<Tw, VEC> ws, wd;
+            if (!UNIFORM) {
+                ws = reinterpret_cast<const Pack<Tw, VEC> *>(wspeed)[o];
+                wd = reinterpret_cast<const Pack<Tw, VEC> *>(wdirn)[o];
+            }
+            Pack<float, VEC> out;
+            Pack<double, VEC> use;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const double spd = UNIFORM ? uni.wspeed[b] : static_cast<double>(ws.v[j]);
+                const double dir = UNIFORM ? uni.wdirn[b] : static_cast<double>(wd.v[j]);
+                double ad = cos((static_cast<double>(a.v[j]) - dir) * kPi / 180.0);
+                ad = ad > 0.0 ? ad : 0.0;                      // np.maximum(0., .)
+                double w = spd * (sin_s[j] * ad);
+                w = w > min_val ? w : min_val;
+                out.v[j] = static_cast<float>(w);
+                if (usable)
+                    use.v[j] = usable_updraft(static_cast<double>(out.v[j]), thr, em1);
+            }
+            if (orograph) reinterpret_cast<Pack<float, VEC> *>(orograph)[o] = out;
+            if (usable) reinterpret_cast<Pack<double, VEC> *>(usable)[o] = use;
+        }
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_threshold(const float *__restrict__ in,
+                                                      double thr, double em1,
+                                                      double *__restrict__ out, size_t n)
+{
+    const size_t nvec = n / VEC;
+    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < nvec;
+         i += static_cast<size_t>(gridDim.x) * kBlock) {
+        const Pack<float, VEC> v = reinterpret_cast<const Pack<float, VEC> *>(in)[i];
+        Pack<double, VEC> o;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+            o.v[j] = usable_updraft(static_cast<double>(v.v[j]), thr, em1);
+        reinterpret_cast<Pack<double, VEC> *>(out)[i] = o;
+    }
+}
+
+static inline int stream_grid(size_t nthreads_needed)
+{
+    size_t b = (nthreads_needed + kBlock - 1) / kBlock;
+    if (b < 1) b = 1;
+    if (b > static_cast<size_t>(kMaxStreamBlocks)) b = kMaxStreamBlocks;
+    return static_cast<int>(b);
+}
+
+static inline bool aligned16(const void *p)
+{   // NULL counts as aligned (optional arrays); 32 B covers Pack<double, 4>
+    return (reinterpret_cast<uintptr_t>(p) & 31u) == 0;
+}
+
+template <typename Tin, typename Tw, bool UNIFORM>
+static int launch_orographic(const void *slope, const void *aspect, const void *wspeed,
+                             const void *wdirn, const UniformWind &uni, double min_val,
+                             float *orograph, double thr, double *usable, size_t ncells,
+                             int batch, hipStream_t st)
+{
+    const double em1 = exp(1.0) - 1.0;
+    const bool vec = (ncells % 4 == 0) && aligned16(slope) && aligned16(aspect) &&
+                     aligned16(wspeed) && aligned16(wdirn) && aligned16(orograph) &&
+                     aligned16(usable);
+    auto s = static_cast<const Tin *>(slope);
+    auto a = static_cast<const Tin *>(aspect);
+    auto ws = static_cast<const Tw *>(wspeed);
+    auto wd = static_cast<const Tw *>(wdirn);
+    if (vec) {
+        hipLaunchKernelGGL((k_orographic<Tin, Tw, UNIFORM, 4>), dim3(stream_grid(ncells / 4)),
+                           dim3(kBlock), 0, st, s, a, ws, wd, uni, min_val, orograph, thr,
+                           em1, usable, ncells, batch);
+    } else {
+        hipLaunchKernelGGL((k_orographic<Tin, Tw, UNIFORM, 1>), dim3(stream_grid(ncells)),
+                           dim3(kBlock), 0, st, s, a, ws, wd, uni, min_val, orograph, thr,
+                           em1, usable, ncells, batch);
+    }
+    SSRS_HIP_CHECK(hipGetLastError());
+    return SSRS_OK;
+}
+
+}  // namespace ssrs
+
+using namespace ssrs;
+
+extern "C" int ssrs_slope_aspect(const void *dem, int dem_type, double res, void *slope,
+                                 void *aspect, int out_type, int rows, int cols,
+                                 void *stream)
+{
+    SSRS_REQUIRE(dem != nullptr, "ssrs_slope_aspect: dem is NULL");
+    SSRS_REQUIRE(rows >= 3 && cols >= 3, "ssrs_slope_aspect: need rows, cols >= 3 (got %d x %d)",
+                 rows, cols);
+    SSRS_REQUIRE(res > 0.0, "ssrs_slope_aspect: res must be > 0");
+    SSRS_REQUIRE((dem_type == SSRS_F32 || dem_type == SSRS_F64) &&
+                     (out_type == SSRS_F32 || out_type == SSRS_F64),
+                 "ssrs_slope_aspect: bad element type");
+    if (!slope && !aspect) return SSRS_OK;
+    const int tx = (cols + TW - 1) / TW, ty = (rows + TH - 1) / TH, nt = tx * ty;
+    hipStream_t st = as_stream(stream);
+#define SA_LAUNCH(TI, TO)                                                              \
+    hipLaunchKernelGGL((k_slope_aspect<TI, TO>), dim3(nt), dim3(kBlock), 0, st,        \
+                       static_cast<const TI *>(dem), res, static_cast<TO *>(slope),    \
+                       static_cast<TO *>(aspect), rows, cols, tx, nt)
+    if (dem_type == SSRS_F64 && out_type == SSRS_F64) SA_LAUNCH(double, double);
+    else if (dem_type == SSRS_F64) SA_LAUNCH(double, float);
+    else if (out_type == SSRS_F64) SA_LAUNCH(float, double);
+    else SA_LAUNCH(float, float);
+#undef SA_LAUNCH
+    SSRS_HIP_CHECK(hipGetLastError());
+    return SSRS_OK;
+}
+
+extern "C" int ssrs_updraft_from_dem(const void *dem, int dem_type, double res,
+                                     double wspeed, double wdirn, double min_val,
+                                     float *orograph, double threshold, double *usable,
+                                     int rows, int cols, void *stream)
+{
+    SSRS_REQUIRE(dem != nullptr, "ssrs_updraft_from_dem: dem is NULL");
+    SSRS_REQUIRE(rows >= 3 && cols >= 3, "ssrs_updraft_from_dem: need rows, cols >= 3");
+    SSRS_REQUIRE(res > 0.0, "ssrs_updraft_from_dem: res must be > 0");
+    SSRS_REQUIRE(dem_type == SSRS_F32 || dem_type == SSRS_F64,
+                 "ssrs_updraft_from_dem: bad element type");
+    SSRS_REQUIRE(!(usable && threshold < 0.0),
+                 "ssrs_updraft_from_dem: usable requested with threshold < 0");
+    if (!orograph && !usable) return SSRS_OK;
+    const int tx = (cols + TW - 1) / TW, ty = (rows + TH - 1) / TH, nt = tx * ty;
+    const double w = wdirn * kPi / 180.0;
+    const double cw = cos(w), sw = sin(w);
+    const double em1 = exp(1.0) - 1.0;
+    hipStream_t st = as_stream(stream);
+    if (dem_type == SSRS_F64)
+        hipLaunchKernelGGL((k_updraft_from_dem<double>), dim3(nt), dim3(kBlock), 0, st,
+                           static_cast<const double *>(dem), res, wspeed, cw, sw, min_val,
+                           orograph, threshold, em1, usable, rows, cols, tx, nt);
+    else
+        hipLaunchKernelGGL((k_updraft_from_dem<float>), dim3(nt), dim3(kBlock), 0, st,
+                           static_cast<const float *>(dem), res, wspeed, cw, sw, min_val,
+                           orograph, threshold, em1, usable, rows, cols, tx, nt);
+    SSRS_HIP_CHECK(hipGetLastError());
+    return SSRS_OK;
+}
+
+extern "C" int ssrs_orographic_updraft(const void *slope, const void *aspect, int in_type,
+                                       const void *wspeed, const void *wdirn, int wind_type,
+                                       const double *wspeed0, const double *wdirn0,
+                                       double min_val, float *orograph, double threshold,
+                                       double *usable, int rows, int cols, int batch,
+                                       void *stream)
+{
+    SSRS_REQUIRE(slope && aspect, "ssrs_orographic_updraft: slope/aspect is NULL");
+    SSRS_REQUIRE(rows > 0 && cols > 0 && batch > 0,
+                 "ssrs_orographic_updraft: rows, cols, batch must be > 0");
+    SSRS_REQUIRE((in_type == SSRS_F32 || in_type == SSRS_F64) &&
+                     (wind_type == SSRS_F32 || wind_type == SSRS_F64),
+                 "ssrs_orographic_updraft: bad element type");
+    SSRS_REQUIRE((wspeed == nullptr) == (wdirn == nullptr),
+                 "ssrs_orographic_updraft: give both wind rasters or neither");
+    SSRS_REQUIRE(!(usable && threshold < 0.0),
+                 "ssrs_orographic_updraft: usable requested with threshold < 0");
+    if (!orograph && !usable) return SSRS_OK;
+    const size_t ncells = static_cast<size_t>(rows) * cols;
+    hipStream_t st = as_stream(stream);
+    UniformWind uni = {};
+    if (wspeed) {
+        if (in_type == SSRS_F32 && wind_type == SSRS_F32)
+            return launch_orographic<float, float, false>(slope, aspect, wspeed, wdirn, uni,
+                                                          min_val, orograph, threshold,
+                                                          usable, ncells, batch, st);
+        if (in_type == SSRS_F32)
+            return launch_orographic<float, double, false>(slope, aspect, wspeed, wdirn, uni,
+                                                           min_val, orograph, threshold,
+                                                           usable, ncells, batch, st);
+        if (wind_type == SSRS_F32)
+            return launch_orographic<double, float, false>(slope, aspect, wspeed, wdirn, uni,
+                                                           min_val, orograph, threshold,
+                                                           usable, ncells, batch, st);
+        return launch_orographic<double, double, false>(slope, aspect, wspeed, wdirn, uni,
+                                                        min_val, orograph, threshold, usable,
+                                                        ncells, batch, st);
+    }
+    SSRS_REQUIRE(wspeed0 && wdirn0, "ssrs_orographic_updraft: uniform mode needs wspeed0/wdirn0");
+    for (int b0 = 0; b0 < batch; b0 += kMaxUniformBatch) {
+        const int nb = batch - b0 < kMaxUniformBatch ? batch - b0 : kMaxUniformBatch;
+        for (int j = 0; j < nb; ++j) {
+            uni.wspeed[j] = wspeed0[b0 + j];
+            uni.wdirn[j] = wdirn0[b0 + j];
+        }
+        float *o = orograph ? orograph + static_cast<size_t>(b0) * ncells : nullptr;
+        double *u = usable ? usable + static_cast<size_t>(b0) * ncells : nullptr;
+        int rc = in_type == SSRS_F32
+                     ? launch_orographic<float, float, true>(slope, aspect, nullptr, nullptr,
+                                                             uni, min_val, o, threshold, u,
+                                                             ncells, nb, st)
+                     : launch_orographic<double, float, true>(slope, aspect, nullptr, nullptr,
+                                                              uni, min_val, o, threshold, u,
+                                                              ncells, nb, st);
+        if (rc != SSRS_OK) return rc;
+    }
+    return SSRS_OK;
+}
+
+extern "C" int ssrs_threshold_updraft(const float *in, double threshold, double *out,
+                                      size_t n, void *stream)
+{
+    SSRS_REQUIRE(in && out, "ssrs_threshold_updraft: NULL pointer");
+    SSRS_REQUIRE(threshold > 0.0, "ssrs_threshold_updraft: threshold must be > 0");
+    if (n == 0) return SSRS_OK;
+    const double em1 = exp(1.0) - 1.0;
+    hipStream_t st = as_stream(stream);
+    if (n % 4 == 0 && aligned16(in) && aligned16(out))
+        hipLaunchKernelGGL((k_threshold<4>), dim3(stream_grid(n / 4)), dim3(kBlock), 0, st, in,
+                           threshold, em1, out, n);
+    else
+        hipLaunchKernelGGL((k_threshold<1>), dim3(stream_grid(n)), dim3(kBlock), 0, st, in,
+                           threshold, em1, out, n);
+    SSRS_HIP_CHECK(hipGetLastError());
+    return SSRS_OK;
+}

@@ -1,0 +1,663 @@
+// K2/K3 -- stochastic track stepper + presence histogram for gfx950 (MI355X).
+//
+// Reference semantics (paths relative to /root/reference):
+//   ssrs/movmodel.py:185-202  get_track_restrictions      -> restriction()
+//   ssrs/movmodel.py:205-217  move_away_from_boundary     -> nudge in step loop
+//   ssrs/movmodel.py:220-244  generate_move_probabilities -> choose_move()
+//   ssrs/movmodel.py:264-318  generate_simulated_tracks   -> k_step_tracks
+//   ssrs/movmodel.py:410-419  compute_presence_counts     -> uint32 atomics
+//   numpy mtrand `choice`     cumsum, /last, searchsorted 'right'
+//
+// Structure (MI355X-first, not a port of the per-track python loop):
+//   * one lane = one track; a launch advances every live track by up to S
+//     steps with its state in registers, then the wave compacts its surviving
+//     lanes into the next launch's index list with one ballot + popcount prefix
+//     and a single atomic per wave.  Track lengths are heavy-tailed (402..26k
+//     steps at 500x600), so later launches run on densely packed waves.
+//   * the per-step uniform is counter-based (rocRAND Philox4x32-10 engine),
+//     a pure function of (seed, global track id, step): any sharding of tracks
+//     over launches / GPUs gives bit-identical trajectories.
+//   * two data paths: 3x3 window gathers of the f64 updraft + f32 potential
+//     rasters (reference-shaped), or one aligned 64-B fetch per step from a
+//     precomputed per-cell transition table (k_transition_table).
+//   * the move decision reproduces the reference's f64 operation order exactly
+//     (pairwise-8 sums, sequential cumsum, f32 potential differences); built
+//     with -ffp-contract=off so no multiply-add is fused.
+#include <rocrand/rocrand_philox4x32_10.h>
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+
+namespace ssrs {
+
+// ------------------------------------------------------------------ constants
+// neighbour k -> (dr, dc) = (k / 3 - 1, k % 3 - 1)            movmodel.py:131-141
+__host__ __device__ constexpr int dr_of(int k) { return k / 3 - 1; }
+__host__ __device__ constexpr int dc_of(int k) { return k % 3 - 1; }
+// f32(1/sqrt(2)) exactly as stored in neighbour_delta_norms_inv
+#define SSRS_NINV_DIAG 0.70710677f
+
+// movmodel.py:185-202: cells within +-45 deg of the previous move d; the
+// initial direction (0,0) allows everything; the centre is never allowed.
+constexpr uint32_t restriction(int d)
+{
+    const int dr = dr_of(d), dc = dc_of(d);
+    uint32_t m = 0;
+    for (int k = 0; k < 9; ++k) {
+        bool ok = false;
+        if (dr == 0 && dc == 0) ok = true;
+        else if (dr != 0 && dc != 0)
+            ok = (dr_of(k) == dr || dr_of(k) == 0) && (dc_of(k) == dc || dc_of(k) == 0);
+        else if (dr == 0) ok = dc_of(k) == dc;
+        else ok = dr_of(k) == dr;
+        if (ok && k != 4) m |= 1u << k;
+    }
+    return m;
+}
+constexpr uint64_t pack_restrictions(int first, int count)
+{
+    uint64_t v = 0;
+    for (int i = 0; i < count; ++i) v |= static_cast<uint64_t>(restriction(first + i)) << (9 * i);
+    return v;
+}
+constexpr uint64_t kRestrictLo = pack_restrictions(0, 7);   // d = 0..6, 63 bits
+constexpr uint64_t kRestrictHi = pack_restrictions(7, 2);   // d = 7, 8
+constexpr uint32_t kAllButCentre = restriction(4);
+static_assert(restriction(0) == 0b000001011u, "(-1,-1) -> k in {0,1,3}");
+static_assert(restriction(7) == 0b111000000u, "(1,0) -> k in {6,7,8}");
+static_assert(kAllButCentre == 0b111101111u, "(0,0) -> all but centre");
+
+__device__ __forceinline__ uint32_t restriction_of(uint32_t d)
+{
+    const uint64_t v = d < 7 ? (kRestrictLo >> (9 * d)) : (kRestrictHi >> (9 * (d - 7)));
+    return static_cast<uint32_t>(v) & 0x1FFu;
+}
+
+// ------------------------------------------------------------------- uniform
+// rocRAND Philox4x32-10: key = seed, counter = (blk, track); one 4-word block
+// serves two steps.  The engine is built and dropped in registers (stateless).
+__device__ __forceinline__ uint4 philox_block(uint64_t seed, uint64_t track, uint64_t blk)
+{
+    rocrand_state_philox4x32_10 st;
+    rocrand_init(seed, track, blk * 4ull, &st);
+    return rocrand4(&st);
+}
+
+__device__ __forceinline__ double words_to_uniform(uint32_t a, uint32_t b)
+{   // numpy legacy random_sample: 53 bits, [0, 1)
+    return (static_cast<double>(a >> 5) * 67108864.0 + static_cast<double>(b >> 6)) *
+           (1.0 / 9007199254740992.0);
+}
+
+__global__ void k_uniform_selftest(uint64_t seed, const uint64_t *track, const uint64_t *step,
+                                   double *out, size_t n)
+{
+    const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
+    if (i >= n) return;
+    const uint4 w = philox_block(seed, track[i], step[i] >> 1);
+    out[i] = (step[i] & 1) ? words_to_uniform(w.z, w.w) : words_to_uniform(w.x, w.y);
+}
+
+// ------------------------------------------------------------ move decision
+__device__ __forceinline__ double sum9(const double *x)
+{   // numpy pairwise summation for n = 9
+    return (((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]))) + x[8];
+}
+
+// generate_move_probabilities (movmodel.py:220-244) followed by
+// np.random.choice's inverse-cdf pick.  w[9] raw weights (w[4] ignored unless NaN).
+__device__ __forceinline__ int choose_move(const double *w, const double *prior, double nu,
+                                           uint32_t mask, double u)
+{
+    double q[9];
+    bool has_nan = false;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) has_nan |= (w[k] != w[k]);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const double v = has_nan ? prior[k] : w[k];
+        q[k] = v > 0.0 ? v : 0.0;                                  // clip(min=0)
+    }
+    q[4] = 0.0;
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        q[k] = q[k] * static_cast<double>((mask >> k) & 1u);
+        any |= (q[k] != 0.0);
+    }
+    if (!any) {                                   // all masked weights are zero
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            q[k] = (k == 4 ? 0.0 : prior[k]) * static_cast<double>((mask >> k) & 1u);
+            any |= (q[k] != 0.0);
+        }
+        if (!any) {                               // prior fully masked as well
+#pragma unroll
+            for (int k = 0; k < 9; ++k) q[k] = prior[k];
+        }
+    }
+    const double s1 = sum9(q);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) q[k] = q[k] / s1;
+    if (nu != 1.0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) q[k] = pow(q[k], nu);
+    }
+    const double s2 = sum9(q);
+    double acc = 0.0;
+    double cdf[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        q[k] = q[k] / s2;
+        acc = acc + q[k];
+        cdf[k] = acc;
+    }
+    int idx = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) idx += (cdf[k] / cdf[8] <= u) ? 1 : 0;
+    return idx;
+}
+
+// Raw 3x3 move weights of movmodel.py:292-306 at an interior cell.
+template <bool HAS_POT>
+__device__ __forceinline__ void window_weights(const double *__restrict__ updraft,
+                                               const float *__restrict__ potential,
+                                               int cols, int row, int col, double *w)
+{
+    const size_t centre = static_cast<size_t>(row) * cols + col;
+    double win[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const double v = updraft[centre + dr_of(j) * cols + dc_of(j)];
+        win[j] = v != v ? v : (v > 1e-06 ? v : 1e-06);            // clip(min=1e-06)
+    }
+    const double ic = 1.0 / win[4];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) w[j] = 2.0 / (ic + 1.0 / win[j]);  // harmonic mean
+    if (HAS_POT) {
+        const float pc = potential[centre];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const float d = pc - potential[centre + dr_of(j) * cols + dc_of(j)];
+            const float ninv = (j == 4) ? 0.f : ((j & 1) ? 1.f : SSRS_NINV_DIAG);
+            const float e = d * ninv;                              // stays f32
+            w[j] = w[j] * static_cast<double>(e);
+        }
+    }
+}
+
+// ------------------------------------------------------------ transition table
+// One thread per cell: 9+9 cached reads, one 64-B row of 8 f64 written.
+__global__ __launch_bounds__(kBlock) void k_transition_table(
+    const double *__restrict__ updraft, const float *__restrict__ potential,
+    double *__restrict__ table, int rows, int cols)
+{
+    const size_t n = static_cast<size_t>(rows) * cols;
+    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * kBlock) {
+        const int row = static_cast<int>(i / cols), col = static_cast<int>(i - static_cast<size_t>(row) * cols);
+        double w[9];
+        bool interior = row > 0 && col > 0 && row < rows - 1 && col < cols - 1;
+        if (interior) {
+            if (potential) window_weights<true>(updraft, potential, cols, row, col, w);
+            else window_weights<false>(updraft, potential, cols, row, col, w);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 9; ++j) w[j] = 0.0;
+        }
+        bool has_nan = false;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) has_nan |= (w[j] != w[j]);
+        double2 *dst = reinterpret_cast<double2 *>(table + i * 8);
+        double o[8];
+#pragma unroll
+        for (int j = 0, k = 0; j < 9; ++j) {
+            if (j == 4) continue;
+            o[k++] = has_nan ? __builtin_nan("") : (w[j] > 0.0 ? w[j] : 0.0);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dst[k] = make_double2(o[2 * k], o[2 * k + 1]);
+    }
+}
+
+// -------------------------------------------------------------------- stepper
+struct alignas(16) TrackState {
+    int32_t pos;     // row | col << 16   (both < 32768)
+    int32_t k;       // moves taken; < 0 = dead (bad start cell)
+    uint32_t dirs;   // last 8 move indices, 4 bits each, newest in bits 0-3
+    uint32_t run;    // AND of restrictions over the whole history (memory == 0)
+};
+
+struct alignas(16) TrackCtl {
+    uint32_t count[4];           // live tracks entering launch i at count[i & 3]
+    uint32_t error;              // != 0: some start cell was outside the raster
+    uint32_t pad;
+    unsigned long long steps;    // total moves taken
+};
+
+enum { MODE_PRIOR = 0, MODE_UPDRAFT = 1, MODE_FLUIDFLOW = 2, MODE_TABLE = 3 };
+
+struct StepArgs {
+    int rows, cols, burnin, memory;
+    long long max_k;
+    double nu;
+    double prior[9];
+    const double *updraft;
+    const float *potential;
+    const double *table;
+    unsigned long long seed, track_base;
+    uint32_t *hist;
+    int16_t *end_rc;
+    int32_t *lengths;
+    int16_t *traj;
+    const long long *traj_off;
+    TrackState *state;
+    const int32_t *list_in;      // NULL = identity (first launch)
+    int32_t *list_out;
+    TrackCtl *ctl;
+    int launch;                  // index of this launch
+    int steps;                   // S
+};
+
+__global__ __launch_bounds__(kBlock) void k_tracks_init(
+    const int32_t *__restrict__ start_rc, long long ntracks, int rows, int cols,
+    uint32_t *hist, int16_t *traj, const long long *traj_off, int32_t *lengths,
+    int16_t *end_rc, TrackState *state, TrackCtl *ctl)
+{
+    const long long t = blockIdx.x * static_cast<long long>(kBlock) + threadIdx.x;
+    if (t == 0) {
+        ctl->count[0] = static_cast<uint32_t>(ntracks);
+        ctl->count[1] = ctl->count[2] = ctl->count[3] = 0;
+        ctl->pad = 0;
+        ctl->steps = 0;
+    }
+    if (t >= ntracks) return;
+    const int row = start_rc[2 * t], col = start_rc[2 * t + 1];
+    TrackState s;
+    s.dirs = 0x44444444u;        // "no move yet" = (0,0) in every history slot
+    s.run = kAllButCentre;
+    if (row < 0 || col < 0 || row >= rows || col >= cols) {
+        atomicOr(&ctl->error, 1u);
+        s.pos = 0;
+        s.k = -1;
+        if (lengths) lengths[t] = 0;
+        if (end_rc) { end_rc[2 * t] = -1; end_rc[2 * t + 1] = -1; }
+    } else {
+        s.pos = row | (col << 16);
+        s.k = 0;
+        if (hist) atomicAdd(&hist[static_cast<size_t>(row) * cols + col], 1u);
+        if (traj)
+            reinterpret_cast<uint32_t *>(traj)[traj_off[t]] =
+                static_cast<uint32_t>(row & 0xFFFF) | (static_cast<uint32_t>(col) << 16);
+    }
+    state[t] = s;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
+{
+    TrackCtl *ctl = a.ctl;
+    const int in_slot = a.launch & 3, out_slot = (a.launch + 1) & 3;
+    const uint32_t nlive = ctl->count[in_slot];
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i == 0) ctl->count[(a.launch + 2) & 3] = 0;   // free slot of launch+1's output
+    // whole waves past the live list leave at once (wave-uniform)
+    if ((i & ~63u) >= nlive) return;
+
+    bool active = i < nlive;
+    const int32_t t = active ? (a.list_in ? a.list_in[i] : static_cast<int32_t>(i)) : 0;
+    TrackState s = {0, -1, 0, 0};
+    if (active) s = a.state[t];
+    active = active && s.k >= 0;
+    int row = s.pos & 0xFFFF, col = (s.pos >> 16) & 0xFFFF;
+    long long k = s.k;
+    uint32_t dirs = s.dirs, run = s.run;
+    const unsigned long long track = a.track_base + static_cast<unsigned long long>(t);
+    const long long toff = (a.traj && active) ? a.traj_off[t] : 0;
+    uint32_t pend_a = 0, pend_b = 0;   // words (2,3) of the current Philox block
+    bool have_pending = false;
+    uint32_t moved = 0;
+
+    for (int it = 0; it < a.steps; ++it) {
+        if (!__any(active)) break;
+        if (active) {
+            // loop head of movmodel.py:285-291
+            bool done = !(k < a.max_k);
+            if (!done) {
+                if (k > a.burnin) {
+                    done = !(0 < row && row < a.rows - 1 && 0 < col && col < a.cols - 1);
+                } else {
+                    if (row <= 1) row += 2; else if (row >= a.rows - 2) row -= 2;
+                    if (col <= 0) col += 2; else if (col >= a.cols - 2) col -= 2;
+                }
+            }
+            if (done) {
+                if (a.lengths) a.lengths[t] = static_cast<int32_t>(k + 1);
+                if (a.end_rc)
+                    reinterpret_cast<uint32_t *>(a.end_rc)[t] =
+                        static_cast<uint32_t>(row & 0xFFFF) | (static_cast<uint32_t>(col) << 16);
+                active = false;
+            } else {
+                // ---- uniform for step k
+                uint32_t wa, wb;
+                if ((k & 1) && have_pending) {
+                    wa = pend_a; wb = pend_b;
+                } else {
+                    const uint4 w4 = philox_block(a.seed, track, static_cast<unsigned long long>(k) >> 1);
+                    if (k & 1) { wa = w4.z; wb = w4.w; }
+                    else { wa = w4.x; wb = w4.y; pend_a = w4.z; pend_b = w4.w; }
+                }
+                have_pending = !(k & 1);
+                const double u = words_to_uniform(wa, wb);
+                // ---- raw weights
+                double w[9];
+                if (MODE == MODE_TABLE) {
+                    const double2 *src = reinterpret_cast<const double2 *>(
+                        a.table + (static_cast<size_t>(row) * a.cols + col) * 8);
+                    const double2 t0 = src[0], t1 = src[1], t2 = src[2], t3 = src[3];
+                    w[0] = t0.x; w[1] = t0.y; w[2] = t1.x; w[3] = t1.y; w[4] = 0.0;
+                    w[5] = t2.x; w[6] = t2.y; w[7] = t3.x; w[8] = t3.y;
+                } else if (MODE == MODE_FLUIDFLOW) {
+                    window_weights<true>(a.updraft, a.potential, a.cols, row, col, w);
+                } else if (MODE == MODE_UPDRAFT) {
+                    window_weights<false>(a.updraft, a.potential, a.cols, row, col, w);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) w[j] = a.prior[j];
+                }
+                // ---- direction memory (movmodel.py:307-309)
+                uint32_t mask = kAllButCentre;
+                if (a.memory == 0) {
+                    mask = run;
+                } else {
+                    uint32_t d = dirs;
+                    for (int j = 0; j < a.memory; ++j) {
+                        mask &= restriction_of(d & 0xFu);
+                        d >>= 4;
+                    }
+                }
+                const int idx = choose_move(w, a.prior, a.nu, mask, u);
+                row += idx / 3 - 1;
+                col += idx % 3 - 1;
+                dirs = (dirs << 4) | static_cast<uint32_t>(idx);
+                run &= restriction_of(static_cast<uint32_t>(idx));
+                ++k;
+                ++moved;
+                if (a.hist) atomicAdd(&a.hist[static_cast<size_t>(row) * a.cols + col], 1u);
+                if (a.traj)
+                    reinterpret_cast<uint32_t *>(a.traj)[toff + k] =
+                        static_cast<uint32_t>(row & 0xFFFF) | (static_cast<uint32_t>(col) << 16);
+            }
+        }
+    }
+
+    // ---- wave-level compaction of the survivors into the next launch's list
+    const unsigned long long live = __ballot(active);
+    const int lane = threadIdx.x & 63;
+    const int nsurv = __popcll(live);
+    uint32_t base = 0;
+    if (lane == 0 && nsurv) base = atomicAdd(&ctl->count[out_slot], static_cast<uint32_t>(nsurv));
+    base = __shfl(base, 0);
+    if (active) {
+        const int rank = __popcll(live & ((1ull << lane) - 1ull));
+        a.list_out[base + rank] = t;
+        TrackState o;
+        o.pos = row | (col << 16);
+        o.k = static_cast<int32_t>(k);
+        o.dirs = dirs;
+        o.run = run;
+        a.state[t] = o;
+    }
+    // one atomic per wave for the step total
+    unsigned long long m = moved;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m += __shfl_down(m, off);
+    if (lane == 0 && m) atomicAdd(&ctl->steps, m);
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Workspace {
+    TrackCtl *ctl;
+    TrackState *state;
+    int32_t *list[2];
+};
+
+static size_t workspace_layout(int64_t n, char *base, Workspace *ws)
+{
+    size_t off = 0;
+    if (ws) ws->ctl = reinterpret_cast<TrackCtl *>(base + off);
+    off = align_up(off + sizeof(TrackCtl), 256);
+    if (ws) ws->state = reinterpret_cast<TrackState *>(base + off);
+    off = align_up(off + sizeof(TrackState) * static_cast<size_t>(n), 256);
+    for (int i = 0; i < 2; ++i) {
+        if (ws) ws->list[i] = reinterpret_cast<int32_t *>(base + off);
+        off = align_up(off + sizeof(int32_t) * static_cast<size_t>(n), 256);
+    }
+    return off;
+}
+
+// pinned host words for the live-count read-back, one set per host thread
+static uint32_t *pinned_counts()
+{
+    static thread_local uint32_t *buf = nullptr;
+    if (!buf && hipHostMalloc(reinterpret_cast<void **>(&buf), 64 * sizeof(uint32_t)) != hipSuccess)
+        buf = nullptr;
+    return buf;
+}
+
+}  // namespace ssrs
+
+using namespace ssrs;
+
+extern "C" int ssrs_track_params_init(SsrsTrackParams *p, int rows, int cols,
+                                      int memory_parameter, double scaling_parameter)
+{
+    SSRS_REQUIRE(p != nullptr, "ssrs_track_params_init: params is NULL");
+    SSRS_REQUIRE(rows >= 5 && cols >= 5, "ssrs_track_params_init: need rows, cols >= 5");
+    *p = SsrsTrackParams{};
+    p->rows = rows;
+    p->cols = cols;
+    p->burnin = static_cast<int32_t>((rows < cols ? rows : cols) / 10.0);   // int(min/10)
+    const double mm = rows / 2.0 * cols / 2.0;                              // movmodel.py:277
+    p->max_moves = static_cast<int64_t>(ceil(mm));
+    p->memory_parameter = memory_parameter;
+    p->scaling_parameter = scaling_parameter;
+    return SSRS_OK;
+}
+
+extern "C" size_t ssrs_tracks_workspace_bytes(int64_t ntracks)
+{
+    if (ntracks < 0) ntracks = 0;
+    return workspace_layout(ntracks, nullptr, nullptr);
+}
+
+extern "C" int ssrs_transition_table_build(const double *updraft, const float *potential,
+                                           double *table, int rows, int cols, void *stream)
+{
+    SSRS_REQUIRE(updraft && table, "ssrs_transition_table_build: updraft/table is NULL");
+    SSRS_REQUIRE(rows >= 3 && cols >= 3, "ssrs_transition_table_build: need rows, cols >= 3");
+    SSRS_REQUIRE((reinterpret_cast<uintptr_t>(table) & 63u) == 0,
+                 "ssrs_transition_table_build: table must be 64-byte aligned");
+    const size_t n = static_cast<size_t>(rows) * cols;
+    size_t blocks = (n + kBlock - 1) / kBlock;
+    if (blocks > static_cast<size_t>(kMaxStreamBlocks) * 4) blocks = kMaxStreamBlocks * 4;
+    hipLaunchKernelGGL(k_transition_table, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0,
+                       as_stream(stream), updraft, potential, table, rows, cols);
+    SSRS_HIP_CHECK(hipGetLastError());
+    return SSRS_OK;
+}
+
+extern "C" int ssrs_uniform_selftest(uint64_t seed, const uint64_t *track, const uint64_t *step,
+                                     double *out, size_t n, void *stream)
+{
+    SSRS_REQUIRE(track && step && out, "ssrs_uniform_selftest: NULL pointer");
+    if (n == 0) return SSRS_OK;
+    hipLaunchKernelGGL(k_uniform_selftest, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256),
+                       0, as_stream(stream), seed, track, step, out, n);
+    SSRS_HIP_CHECK(hipGetLastError());
+    return SSRS_OK;
+}
+
+extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updraft,
+                                    const float *potential, const double *table,
+                                    const int32_t *start_rc, int64_t ntracks, uint64_t seed,
+                                    uint64_t track_id_base, uint32_t *hist, int16_t *end_rc,
+                                    int32_t *lengths, int16_t *traj, const int64_t *traj_offsets,
+                                    void *workspace, size_t workspace_bytes,
+                                    SsrsTrackStats *stats, void *stream)
+{
+    SSRS_REQUIRE(p != nullptr, "ssrs_tracks_simulate: params is NULL");
+    SSRS_REQUIRE(p->rows >= 5 && p->cols >= 5, "ssrs_tracks_simulate: need rows, cols >= 5 (got %d x %d)",
+                 p->rows, p->cols);
+    SSRS_REQUIRE(p->rows <= 32767 && p->cols <= 32767,
+                 "ssrs_tracks_simulate: rows, cols must fit int16 trajectories (<= 32767)");
+    SSRS_REQUIRE(p->memory_parameter >= 0 && p->memory_parameter <= 8,
+                 "ssrs_tracks_simulate: memory_parameter must be in 0..8 (got %d)",
+                 p->memory_parameter);
+    SSRS_REQUIRE(p->max_moves >= 0 && p->max_moves < (1ll << 31) - 1,
+                 "ssrs_tracks_simulate: max_moves out of range");
+    SSRS_REQUIRE(p->burnin >= 0, "ssrs_tracks_simulate: burnin must be >= 0");
+    SSRS_REQUIRE(ntracks >= 0 && ntracks < (1ll << 31) - 64, "ssrs_tracks_simulate: bad ntracks");
+    SSRS_REQUIRE(!(potential && !updraft && !table),
+                 "ssrs_tracks_simulate: potential_field needs updraft_field (reference raises)");
+    SSRS_REQUIRE(!(traj && !traj_offsets), "ssrs_tracks_simulate: traj needs traj_offsets");
+    SSRS_REQUIRE(!(table && (reinterpret_cast<uintptr_t>(table) & 63u)),
+                 "ssrs_tracks_simulate: table must be 64-byte aligned");
+    if (stats) *stats = SsrsTrackStats{};
+    if (ntracks == 0) return SSRS_OK;
+    SSRS_REQUIRE(start_rc != nullptr, "ssrs_tracks_simulate: start_rc is NULL");
+    SSRS_REQUIRE(workspace && workspace_bytes >= ssrs_tracks_workspace_bytes(ntracks),
+                 "ssrs_tracks_simulate: workspace too small (need %zu bytes)",
+                 ssrs_tracks_workspace_bytes(ntracks));
+    SSRS_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0,
+                 "ssrs_tracks_simulate: workspace must be 256-byte aligned");
+
+    hipStream_t st = as_stream(stream);
+    Workspace ws;
+    workspace_layout(ntracks, static_cast<char *>(workspace), &ws);
+    uint32_t *host_counts = pinned_counts();
+    SSRS_REQUIRE(host_counts != nullptr, "ssrs_tracks_simulate: hipHostMalloc failed");
+
+    const int S = p->steps_per_launch > 0 ? p->steps_per_launch : 256;
+    const bool profile = (p->flags & SSRS_TRACKS_PROFILE) != 0;
+    const int mode = table ? MODE_TABLE : (updraft ? (potential ? MODE_FLUIDFLOW : MODE_UPDRAFT)
+                                                   : MODE_PRIOR);
+
+    SSRS_HIP_CHECK(hipMemsetAsync(ws.ctl, 0, sizeof(TrackCtl), st));
+    hipEvent_t ev_first = nullptr, ev_last = nullptr;
+    SSRS_HIP_CHECK(hipEventCreate(&ev_first));
+    SSRS_HIP_CHECK(hipEventCreate(&ev_last));
+    SSRS_HIP_CHECK(hipEventRecord(ev_first, st));
+    {
+        const unsigned blocks = static_cast<unsigned>((ntracks + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(k_tracks_init, dim3(blocks), dim3(kBlock), 0, st, start_rc,
+                           static_cast<long long>(ntracks), p->rows, p->cols, hist, traj,
+                           reinterpret_cast<const long long *>(traj_offsets), lengths, end_rc,
+                           ws.state, ws.ctl);
+        SSRS_HIP_CHECK(hipGetLastError());
+    }
+
+    StepArgs a = {};
+    a.rows = p->rows; a.cols = p->cols; a.burnin = p->burnin; a.memory = p->memory_parameter;
+    a.max_k = p->max_moves; a.nu = p->scaling_parameter;
+    for (int j = 0; j < 9; ++j) a.prior[j] = p->prior[j];
+    a.updraft = updraft; a.potential = potential; a.table = table;
+    a.seed = seed; a.track_base = track_id_base;
+    a.hist = hist; a.end_rc = end_rc; a.lengths = lengths; a.traj = traj;
+    a.traj_off = reinterpret_cast<const long long *>(traj_offsets);
+    a.state = ws.state; a.ctl = ws.ctl; a.steps = S;
+
+    // Launch loop.  Launches are queued kBatch deep; the live count of a batch
+    // is copied back asynchronously and examined while the next batch runs, so
+    // the GPU never waits on the host.  Launches past the end see count 0.
+    constexpr int kBatch = 4, kRing = 8;
+    hipEvent_t ev_batch[kRing];
+    for (int i = 0; i < kRing; ++i) SSRS_HIP_CHECK(hipEventCreate(&ev_batch[i]));
+    std::vector<hipEvent_t> ev_prof;
+    int launch = 0;
+    uint32_t upper = static_cast<uint32_t>(ntracks);   // bound on the live count
+    int batches = 0, checked = 0;
+    bool finished = false;
+    int rc = SSRS_OK;
+    // Termination: every live track either finishes or takes S moves per
+    // launch and k < max_moves, so the live count reaches 0.
+    while (!finished && rc == SSRS_OK) {
+        for (int j = 0; j < kBatch; ++j, ++launch) {
+            a.launch = launch;
+            a.list_in = launch == 0 ? nullptr : ws.list[launch & 1];
+            a.list_out = ws.list[(launch + 1) & 1];
+            const unsigned blocks = (upper + kBlock - 1) / kBlock;
+            if (profile) {
+                hipEvent_t e;
+                if (hipEventCreate(&e) == hipSuccess) { hipEventRecord(e, st); ev_prof.push_back(e); }
+            }
+            switch (mode) {
+            case MODE_TABLE: hipLaunchKernelGGL(k_step_tracks<MODE_TABLE>, dim3(blocks), dim3(kBlock), 0, st, a); break;
+            case MODE_FLUIDFLOW: hipLaunchKernelGGL(k_step_tracks<MODE_FLUIDFLOW>, dim3(blocks), dim3(kBlock), 0, st, a); break;
+            case MODE_UPDRAFT: hipLaunchKernelGGL(k_step_tracks<MODE_UPDRAFT>, dim3(blocks), dim3(kBlock), 0, st, a); break;
+            default: hipLaunchKernelGGL(k_step_tracks<MODE_PRIOR>, dim3(blocks), dim3(kBlock), 0, st, a); break;
+            }
+            if (hipGetLastError() != hipSuccess) { rc = set_error(SSRS_ERR_HIP, "stepper launch failed"); break; }
+        }
+        if (rc != SSRS_OK) break;
+        // survivors of this batch = input count of the next launch
+        const int slot = batches % kRing;
+        if (hipMemcpyAsync(&host_counts[slot], &ws.ctl->count[launch & 3], sizeof(uint32_t),
+                           hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipEventRecord(ev_batch[slot], st) != hipSuccess) {
+            rc = set_error(SSRS_ERR_HIP, "live-count read-back failed");
+            break;
+        }
+        ++batches;
+        // examine every batch but the one just queued (it keeps the GPU busy)
+        while (checked < batches - 1) {
+            const int cs = checked % kRing;
+            if (hipEventSynchronize(ev_batch[cs]) != hipSuccess) { rc = set_error(SSRS_ERR_HIP, "event sync failed"); break; }
+            const uint32_t c = host_counts[cs];
+            ++checked;
+            if (c == 0) { finished = true; break; }
+            upper = c;   // the live count only shrinks; a stale bound is safe
+        }
+    }
+    if (profile) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) == hipSuccess) { hipEventRecord(e, st); ev_prof.push_back(e); }
+    }
+    hipEventRecord(ev_last, st);
+    // fetch step total + error flag
+    TrackCtl host_ctl = {};
+    if (rc == SSRS_OK) {
+        if (hipMemcpyAsync(&host_counts[32], ws.ctl, sizeof(TrackCtl), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess)
+            rc = set_error(SSRS_ERR_HIP, "final read-back failed");
+        else
+            memcpy(&host_ctl, &host_counts[32], sizeof(TrackCtl));
+    } else {
+        hipStreamSynchronize(st);
+    }
+    if (stats && rc == SSRS_OK) {
+        stats->total_steps = static_cast<int64_t>(host_ctl.steps);
+        stats->launches = launch;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev_first, ev_last) == hipSuccess) stats->wall_ms = ms;
+        if (profile) {
+            float sum = 0.f;
+            for (size_t i = 0; i + 1 < ev_prof.size(); ++i)
+                if (hipEventElapsedTime(&ms, ev_prof[i], ev_prof[i + 1]) == hipSuccess) sum += ms;
+            stats->kernel_ms = sum;
+        }
+    }
+    for (hipEvent_t e : ev_prof) hipEventDestroy(e);
+    for (int i = 0; i < kRing; ++i) hipEventDestroy(ev_batch[i]);
+    hipEventDestroy(ev_first);
+    hipEventDestroy(ev_last);
+    if (rc != SSRS_OK) return rc;
+    if (host_ctl.error)
+        return set_error(SSRS_ERR_START, "ssrs_tracks_simulate: a start cell lies outside the %d x %d raster",
+                         p->rows, p->cols);
+    return SSRS_OK;
+}

@@ -1,0 +1,213 @@
+"""Track stepper host side (K2/K3), behind the reference's function names
+(/root/reference/ssrs/movmodel.py).  The per-step work runs in
+libssrs_hip.so; this module only prepares arguments (start cells, the
+directional prior, which needs the host's cos) and owns the device buffers.
+
+Random stream: the reference draws from numpy's global MT19937 inside a fork
+pool (movmodel.py:312, simulator.py:360), which is irreproducible; here
+u(seed, track_id, step) is Philox4x32-10 (include/ssrs_hip.h "Uniform
+contract"), so results do not depend on how tracks are sharded.
+"""
+import ctypes as C
+from math import floor, ceil
+
+import numpy as np
+import torch
+
+from . import _native as nat
+from ._device import device, stream_ptr, to_dev, is_tensor
+
+# movmodel.py:131-141
+neighbour_deltas = [np.array([k // 3 - 1, k % 3 - 1]) for k in range(9)]
+neighbour_delta_norms_inv = np.array(
+    [[1 / np.sqrt(2.), 1., 1 / np.sqrt(2.)], [1., 0., 1.],
+     [1 / np.sqrt(2.), 1., 1 / np.sqrt(2.)]], dtype=np.float32)
+
+
+def get_starting_indices(ntracks, sbounds, stype, twidth, tres):
+    """movmodel.py:144-182 -> (rows, cols) int arrays.  Host-side integer logic;
+    'random' consumes numpy's legacy global stream with the same single
+    np.random.randint call as the reference, so a seeded run picks the same
+    start cells."""
+    if (sbounds[1] < sbounds[0] or sbounds[3] < sbounds[2] or sbounds[0] < 0.
+            or sbounds[2] < 0. or sbounds[1] > twidth[0] or sbounds[3] > twidth[1]):
+        raise ValueError('track_start_region incompatible with terrain_width!')
+    res_km = tres / 1000.
+    x_max = ceil(twidth[0] / res_km)
+    y_max = ceil(twidth[1] / res_km)
+    x_lo = min(max(floor(sbounds[0] / res_km) - 1, 1), x_max - 2)
+    x_hi = max(min(ceil(sbounds[1] / res_km), x_max - 1), 2)
+    y_lo = min(max(floor(sbounds[2] / res_km) - 1, 1), y_max - 2)
+    y_hi = max(min(ceil(sbounds[3] / res_km), y_max - 1), 2)
+    nx, ny = x_hi - x_lo, y_hi - y_lo
+    base_count = nx * ny
+
+    def cell(idx):      # candidate list is x-major: idx = ix * ny + iy
+        idx = np.asarray(idx, dtype=np.int64)
+        return y_lo + idx % ny, x_lo + idx // ny
+
+    if stype == 'structured':
+        pick = np.round(np.linspace(0, base_count - 1, ntracks % base_count)).astype(np.int64)
+        if ntracks > base_count:
+            whole = np.tile(np.arange(base_count, dtype=np.int64), ntracks // base_count)
+            idx = np.concatenate((whole, pick))
+        else:
+            idx = pick
+    elif stype == 'random':
+        idx = np.random.randint(0, base_count, ntracks)
+    else:
+        raise ValueError((f'Model:Invalid sim_start_type of {stype}\n'
+                          'Options: structured, random'))
+    rows, cols = cell(idx)
+    return rows.astype(int), cols.astype(int)
+
+
+def get_directional_probs(theta):
+    """movmodel.py:247-257: cos lobe toward heading theta (radians), entries
+    below 0.01 zeroed, row order flipped so that +row = north."""
+    ang = np.array([[3 * np.pi / 4, np.pi, 5 * np.pi / 4],
+                    [np.pi / 2, np.nan, 3 * np.pi / 2],
+                    [np.pi / 4, 0., 7 * np.pi / 4]])
+    lobe = np.cos(ang + theta)
+    lobe[1, 1] = 0.
+    lobe[lobe < 0.01] = 0.
+    return lobe.flatten()
+
+
+def make_track_params(grid_shape, move_dirn, memory_parameter=1, scaling_parameter=1.,
+                      steps_per_launch=0, profile=False):
+    rows, cols = int(grid_shape[0]), int(grid_shape[1])
+    p = nat.SsrsTrackParams()
+    nat.check(nat.lib().ssrs_track_params_init(C.byref(p), rows, cols, int(memory_parameter),
+                                               C.c_double(scaling_parameter)))
+    prior = get_directional_probs(move_dirn * np.pi / 180.)
+    for k in range(9):
+        p.prior[k] = float(prior[k])
+    p.steps_per_launch = int(steps_per_launch)
+    p.flags = nat.SSRS_TRACKS_PROFILE if profile else 0
+    return p
+
+
+def build_transition_table(updraft, potential):
+    """Per-cell move weights (8 x f64 per cell) for the table stepper."""
+    upd = to_dev(updraft, torch.float64)
+    pot = to_dev(potential, torch.float32)
+    rows, cols = int(upd.shape[0]), int(upd.shape[1])
+    if pot is not None and tuple(pot.shape) != (rows, cols):
+        raise ValueError('updraft and potential shapes differ')
+    table = torch.empty((rows, cols, 8), dtype=torch.float64, device=upd.device)
+    nat.check(nat.lib().ssrs_transition_table_build(
+        nat.ptr(upd), nat.ptr(pot), nat.ptr(table), rows, cols, stream_ptr()))
+    return table
+
+
+class TrackBatch:
+    """Result of simulate_tracks: device tensors + lazy host views."""
+
+    def __init__(self, lengths, ends, hist, traj, offsets, stats):
+        self.lengths = lengths        # int32 (n)          trajectory points per track
+        self.ends = ends              # int16 (n, 2)       last point [row, col]
+        self.hist = hist              # uint32-in-int32 (rows, cols) or None
+        self.traj = traj              # int16 (sum lengths, 2) or None
+        self.offsets = offsets        # int64 (n + 1) or None
+        self.stats = stats            # dict(total_steps, launches, kernel_ms, wall_ms)
+
+    def tracks(self):
+        """List[int16 (n_i, 2)] like the reference's pool.map result."""
+        if self.traj is None:
+            raise ValueError('simulate_tracks was called with want_tracks=False')
+        traj = self.traj.cpu().numpy()
+        off = self.offsets.cpu().numpy()
+        return [traj[off[i]:off[i + 1]] for i in range(off.size - 1)]
+
+
+def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
+                    scaling_parameter=1., updraft_field=None, potential_field=None, *,
+                    seed=0, track_id_base=0, table=None, use_table=None, hist=None,
+                    want_hist=True, want_tracks=False, steps_per_launch=0, profile=False):
+    """generate_simulated_tracks for a whole batch (movmodel.py:264-318 under
+    simulator.py:360-369) + presence histogram (movmodel.py:410-419).
+
+    starts: int (n, 2) [row, col].  updraft_field f64 / potential_field f32
+    rasters (numpy or CUDA tensors); both None = 'drw'.  `table` (from
+    build_transition_table) or use_table=True selects the one-fetch-per-step
+    path; default: table when it pays (many steps per cell).
+    `hist` (int32/uint32 CUDA tensor) is accumulated into when given.
+    """
+    rows, cols = int(grid_shape[0]), int(grid_shape[1])
+    dev = device()
+    st = to_dev(np.asarray(starts) if not is_tensor(starts) else starts, torch.int32)
+    st = st.reshape(-1, 2).contiguous()
+    n = int(st.shape[0])
+    upd = to_dev(updraft_field, torch.float64)
+    pot = to_dev(potential_field, torch.float32)
+    for name, f in (('updraft_field', upd), ('potential_field', pot)):
+        if f is not None and tuple(f.shape) != (rows, cols):
+            raise ValueError(f'{name} shape {tuple(f.shape)} != grid_shape {(rows, cols)}')
+    if pot is not None and upd is None:
+        raise ValueError('potential_field needs updraft_field')
+    if table is None and upd is not None:
+        if use_table is None:
+            # building costs ~1 window evaluation per cell; pays once the batch
+            # takes more steps than that (>= ~rows steps per track)
+            use_table = n * rows >= 4 * rows * cols
+        if use_table:
+            table = build_transition_table(upd, pot)
+    p = make_track_params((rows, cols), move_dirn, memory_parameter, scaling_parameter,
+                          steps_per_launch, profile)
+    if hist is None and want_hist:
+        hist = torch.zeros((rows, cols), dtype=torch.int32, device=dev)
+    lengths = torch.empty(n, dtype=torch.int32, device=dev)
+    ends = torch.empty((n, 2), dtype=torch.int16, device=dev)
+    ws_bytes = nat.lib().ssrs_tracks_workspace_bytes(n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    stats = nat.SsrsTrackStats()
+
+    def run(hist_t, traj_t, off_t):
+        nat.check(nat.lib().ssrs_tracks_simulate(
+            C.byref(p), nat.ptr(upd), nat.ptr(pot), nat.ptr(table), nat.ptr(st),
+            C.c_int64(n), C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF),
+            C.c_uint64(int(track_id_base)), nat.ptr(hist_t), nat.ptr(ends),
+            nat.ptr(lengths), nat.ptr(traj_t), nat.ptr(off_t), nat.ptr(ws),
+            C.c_size_t(ws_bytes), C.byref(stats), stream_ptr()))
+
+    traj = offsets = None
+    if want_tracks:
+        # pass 1: lengths only; pass 2 replays the same counter-based streams
+        # and writes every point at its final offset (no per-track cap).
+        run(None, None, None)
+        offsets = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(lengths, 0, out=offsets[1:])
+        total = int(offsets[-1].item())
+        traj = torch.empty((total, 2), dtype=torch.int16, device=dev)
+        run(hist, traj, offsets)
+    else:
+        run(hist, None, None)
+    return TrackBatch(lengths, ends, hist, traj, offsets,
+                      dict(total_steps=int(stats.total_steps), launches=int(stats.launches),
+                           kernel_ms=float(stats.kernel_ms), wall_ms=float(stats.wall_ms)))
+
+
+def generate_simulated_tracks(move_dirn, start_location, grid_shape, memory_parameter=1,
+                              scaling_parameter=1., updraft_field=None, potential_field=None,
+                              *, seed=0, track_id=0):
+    """Reference signature (movmodel.py:264-272) for ONE track -> int16 (n, 2).
+    The two keyword-only arguments name the track's random stream."""
+    res = simulate_tracks(move_dirn, [list(start_location)], grid_shape, memory_parameter,
+                          scaling_parameter, updraft_field, potential_field, seed=seed,
+                          track_id_base=track_id, use_table=False, want_hist=False,
+                          want_tracks=True)
+    return res.tracks()[0]
+
+
+def uniforms(seed, track, step):
+    """u(seed, track, step) evaluated on the device (rocRAND Philox engine)."""
+    tr = to_dev(np.asarray(track, dtype=np.uint64).view(np.int64), torch.int64).reshape(-1)
+    sp = to_dev(np.asarray(step, dtype=np.uint64).view(np.int64), torch.int64).reshape(-1)
+    if tr.numel() != sp.numel():
+        raise ValueError('track and step lengths differ')
+    out = torch.empty(tr.numel(), dtype=torch.float64, device=tr.device)
+    nat.check(nat.lib().ssrs_uniform_selftest(
+        C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), nat.ptr(tr), nat.ptr(sp), nat.ptr(out),
+        C.c_size_t(tr.numel()), stream_ptr()))
+    return out.cpu().numpy()

@@ -1,0 +1,250 @@
+"""K2/K3 parity on the MI355X: the HIP stepper (through the C ABI) must be
+BIT-EXACT -- trajectories, lengths, endpoints, histogram -- against
+  (a) trajectories the reference itself produced (tests/golden/g7, g8), and
+  (b) the C oracle on fresh seeded inputs.
+Integer path => no tolerance anywhere in this file (nu == 1).
+"""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+G7_CASES = ['ff_m1', 'ff_m3', 'ff_d135_m2', 'drw_m1', 'drw_d250_m3']
+
+
+def split(flat, lengths):
+    off = np.concatenate([[0], np.cumsum(lengths)])
+    return [flat[off[i]:off[i + 1]] for i in range(len(lengths))]
+
+
+def test_uniform_contract_matches_oracle(gpu):
+    """rocRAND Philox engine on the device == Random123-pinned oracle."""
+    from ssrs_amd import movmodel
+    from oracle.philox import uniform53
+    rng = np.random.default_rng(1)
+    track = rng.integers(0, 2**63, 4096, dtype=np.uint64)
+    step = rng.integers(0, 2**40, 4096, dtype=np.uint64)
+    track[:8] = [0, 1, 2, 3, 2**32 - 1, 2**32, 2**32 + 1, 2**64 - 1]
+    step[:8] = [0, 1, 2, 3, 2**33 - 1, 2**33, 2**33 + 1, 7]
+    for seed in (0, 30, 2**64 - 1, 0x123456789ABCDEF):
+        got = movmodel.uniforms(seed, track, step)
+        want = uniform53(seed, track, step)
+        assert np.array_equal(got, want)
+        assert got.min() >= 0.0 and got.max() < 1.0
+
+
+@pytest.mark.parametrize('tag', G7_CASES)
+@pytest.mark.parametrize('use_table', [False, True])
+def test_g7_reference_trajectories(gpu, golden, tag, use_table):
+    from ssrs_amd import movmodel
+    g = golden('g7_tracks.npz')
+    dirn, mem, nu, has_u, has_p = g[tag + '_params']
+    if use_table and not has_u:
+        pytest.skip('drw has no table')
+    starts = np.stack([g['start_rows'], g['start_cols']], 1)
+    res = movmodel.simulate_tracks(
+        float(dirn), starts, (96, 128), int(mem), float(nu),
+        g['updraft'] if has_u else None, g['potential'] if has_p else None,
+        seed=int(g['seed']), use_table=use_table, want_tracks=True, steps_per_launch=16)
+    lens = res.lengths.cpu().numpy()
+    assert np.array_equal(lens, g[tag + '_lengths'])
+    want = split(g[tag + '_tracks'], g[tag + '_lengths'])
+    got = res.tracks()
+    for t, (a, b) in enumerate(zip(got, want)):
+        assert a.dtype == np.int16 and np.array_equal(a, b), f'track {t} differs'
+    assert np.array_equal(res.ends.cpu().numpy(), np.array([w[-1] for w in want]))
+    hist = np.zeros((96, 128), dtype=np.int64)
+    np.add.at(hist, (g[tag + '_tracks'][:, 0].astype(int), g[tag + '_tracks'][:, 1].astype(int)), 1)
+    assert np.array_equal(res.hist.cpu().numpy().astype(np.int64), hist)
+    assert res.stats['total_steps'] == int(lens.sum() - len(lens))
+
+
+def test_single_track_reference_signature(gpu, golden):
+    from ssrs_amd import movmodel
+    g = golden('g7_tracks.npz')
+    want = split(g['ff_m1_tracks'], g['ff_m1_lengths'])
+    for t in (0, 5, 63):
+        tr = movmodel.generate_simulated_tracks(
+            0., [int(g['start_rows'][t]), int(g['start_cols'][t])], (96, 128), 1, 1.,
+            g['updraft'], g['potential'], seed=int(g['seed']), track_id=t)
+        assert np.array_equal(tr, want[t])
+
+
+def test_nu_half_within_tolerance(gpu, golden):
+    """nu != 1 uses pow(): not bit-reproducible across libms, so only the
+    statistics are compared."""
+    from ssrs_amd import movmodel
+    g = golden('g7_tracks.npz')
+    starts = np.stack([g['start_rows'], g['start_cols']], 1)
+    res = movmodel.simulate_tracks(0., starts, (96, 128), 1, 0.5, g['updraft'], g['potential'],
+                                   seed=int(g['seed']), use_table=False)
+    lens = res.lengths.cpu().numpy()
+    same = (lens == g['ff_m1_nu05_lengths']).mean()
+    assert same >= 0.9, f'only {same:.2f} of nu=0.5 tracks have the reference length'
+
+
+def test_c1_golden_1000_tracks(gpu, golden):
+    """BASELINE config 1 (500 x 600 @100 m, 1000 tracks, seed 30): every
+    trajectory equals the reference's (sha256 over all int16 points)."""
+    from ssrs_amd import movmodel, layers
+    g = golden('g8_c1.npz')
+    shape = (500, 600)
+    upd = layers.get_above_threshold_speed(g['orograph_f32'], 0.75)
+    starts = np.stack([g['start_rows'], g['start_cols']], 1)
+    for use_table in (False, True):
+        res = movmodel.simulate_tracks(0., starts, shape, 1, 1., upd, g['potential'],
+                                       seed=int(g['seed']), use_table=use_table,
+                                       want_tracks=True)
+        assert np.array_equal(res.lengths.cpu().numpy(), g['lengths'])
+        assert np.array_equal(res.ends.cpu().numpy(), g['ends'])
+        tracks = res.tracks()
+        sha = hashlib.sha256()
+        for t in tracks:
+            sha.update(np.ascontiguousarray(t, dtype='<i2').tobytes())
+        assert sha.hexdigest() == str(g['traj_sha256'])
+        assert np.array_equal(res.hist.cpu().numpy(), g['hist'])
+        first = split(g['first_tracks'], g['first_lengths'])
+        for a, b in zip(tracks[:8], first):
+            assert np.array_equal(a, b)
+
+
+def _random_field_case(rows, cols, seed):
+    from ssrs_amd.synthetic import synthetic_dem
+    from oracle import ssrs_oracle as orc
+    rng = np.random.default_rng(seed)
+    z = synthetic_dem((rows, cols), 100., seed=seed)
+    slope = orc.compute_slope_degrees(z, 100.)
+    aspect = orc.compute_aspect_degrees(z, 100.)
+    oro = orc.compute_orographic_updraft(10., 270., slope, aspect).astype(np.float32)
+    upd = orc.get_above_threshold_speed(oro, 0.75)
+    # rough potential: ramp + noise, so that E/W/S moves and dead ends occur
+    pot = (1000. * (1 - np.arange(rows)[:, None] / (rows - 1.)) +
+           rng.normal(0, 1.5, (rows, cols))).astype(np.float32)
+    return upd, pot
+
+
+@pytest.mark.parametrize('mem,dirn', [(1, 0.), (2, 40.), (8, 180.), (0, 0.)])
+def test_vs_c_oracle_fresh_inputs(gpu, mem, dirn):
+    from ssrs_amd import movmodel
+    from oracle import c_oracle
+    rows, cols = 150, 170
+    upd, pot = _random_field_case(rows, cols, 99 + mem)
+    rng = np.random.default_rng(mem)
+    n = 700
+    starts = np.stack([rng.integers(0, rows, n), rng.integers(0, cols, n)], 1)
+    ref = c_oracle.simulate_tracks(dirn, starts, (rows, cols), mem, 1., upd, pot, seed=7,
+                                   track_id_base=1000)
+    for use_table in (False, True):
+        res = movmodel.simulate_tracks(dirn, starts, (rows, cols), mem, 1., upd, pot, seed=7,
+                                       track_id_base=1000, use_table=use_table,
+                                       want_tracks=True, steps_per_launch=64)
+        assert np.array_equal(res.lengths.cpu().numpy(), ref['lengths'])
+        assert np.array_equal(res.ends.cpu().numpy(), ref['ends'])
+        assert np.array_equal(res.hist.cpu().numpy().view(np.uint32), ref['hist'])
+        for a, b in zip(res.tracks(), ref['tracks']):
+            assert np.array_equal(a, b)
+
+
+def test_nan_and_zero_fields_take_reference_fallbacks(gpu):
+    """NaN weights -> directional prior (movmodel.py:228-230); all-zero masked
+    weights -> prior (:234-240).  Flat potential gives all-zero weights."""
+    from ssrs_amd import movmodel
+    from oracle import c_oracle
+    rows, cols = 60, 70
+    upd = np.full((rows, cols), 0.5)
+    pot = np.full((rows, cols), 3.0, dtype=np.float32)          # zero differences
+    upd[20:25, 30:40] = np.nan
+    pot[40:42, 10:60] = np.nan
+    rng = np.random.default_rng(3)
+    starts = np.stack([rng.integers(0, 12, 300), rng.integers(0, cols, 300)], 1)
+    ref = c_oracle.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=5)
+    for use_table in (False, True):
+        res = movmodel.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=5,
+                                       use_table=use_table, want_tracks=True)
+        for a, b in zip(res.tracks(), ref['tracks']):
+            assert np.array_equal(a, b)
+
+
+def test_updraft_only_mode(gpu):
+    """No potential: harmonic-mean weights only (MODE_UPDRAFT kernel)."""
+    from ssrs_amd import movmodel
+    from oracle import c_oracle
+    rows, cols = 24, 26
+    rng = np.random.default_rng(11)
+    upd = rng.uniform(0., 2., (rows, cols))
+    starts = np.stack([rng.integers(0, rows, 128), rng.integers(0, cols, 128)], 1)
+    ref = c_oracle.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, None, seed=1)
+    for use_table in (False, True):
+        res = movmodel.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, None, seed=1,
+                                       use_table=use_table, want_tracks=True, steps_per_launch=7)
+        assert np.array_equal(res.lengths.cpu().numpy(), ref['lengths'])
+        for a, b in zip(res.tracks(), ref['tracks']):
+            assert np.array_equal(a, b)
+
+
+def test_max_moves_exit(gpu):
+    """A vortex potential keeps tracks orbiting until k == max_moves
+    (rows/2*cols/2, movmodel.py:277,285): exercises the non-border exit and a
+    launch count that is not a multiple of steps_per_launch."""
+    from ssrs_amd import movmodel
+    from oracle import c_oracle
+    rows, cols = 31, 33
+    r = np.arange(rows)[:, None] - 15.
+    c = np.arange(cols)[None, :] - 16.
+    theta = np.mod(np.arctan2(r, c), 2 * np.pi)
+    pot = (100. * (2 * np.pi - theta) + 2. * (np.hypot(r, c) - 8.)**2).astype(np.float32)
+    upd = np.ones((rows, cols))
+    rng = np.random.default_rng(11)
+    starts = np.stack([rng.integers(5, 26, 128), rng.integers(5, 28, 128)], 1)
+    ref = c_oracle.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=1)
+    assert ref['lengths'].max() == 257 and (ref['lengths'] == 257).sum() > 100
+    for use_table in (False, True):
+        res = movmodel.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=1,
+                                       use_table=use_table, want_tracks=True, steps_per_launch=50)
+        assert np.array_equal(res.lengths.cpu().numpy(), ref['lengths'])
+        for a, b in zip(res.tracks(), ref['tracks']):
+            assert np.array_equal(a, b)
+
+
+def test_edge_cases_and_errors(gpu):
+    from ssrs_amd import movmodel
+    upd = np.ones((40, 50))
+    pot = np.zeros((40, 50), dtype=np.float32)
+    res = movmodel.simulate_tracks(0., np.zeros((0, 2), dtype=int), (40, 50), 1, 1., upd, pot)
+    assert res.lengths.numel() == 0 and int(res.hist.sum()) == 0
+    with pytest.raises(ValueError):     # start outside the raster
+        movmodel.simulate_tracks(0., [[40, 3]], (40, 50), 1, 1., upd, pot)
+    with pytest.raises(ValueError):     # reference raises for potential without updraft
+        movmodel.simulate_tracks(0., [[4, 3]], (40, 50), 1, 1., None, pot)
+    with pytest.raises(ValueError):
+        movmodel.simulate_tracks(0., [[4, 3]], (40, 50), 9, 1., upd, pot)
+    with pytest.raises(ValueError):
+        movmodel.simulate_tracks(0., [[4, 3]], (40, 51), 1, 1., upd, pot)
+
+
+def test_sharding_invariance_and_hist_checksum(gpu):
+    """Tracks split over 'ranks' with track_id_base offsets == one big run:
+    the property the multi-GPU path relies on.  Also sum(hist) == sum(lengths)."""
+    from ssrs_amd import movmodel
+    rows, cols = 300, 320
+    upd, pot = _random_field_case(rows, cols, 4)
+    rng = np.random.default_rng(8)
+    n = 5000
+    starts = np.stack([rng.integers(2, 30, n), rng.integers(0, cols, n)], 1)
+    whole = movmodel.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=30)
+    parts = None
+    lens = []
+    for lo, hi in [(0, 1234), (1234, 3000), (3000, 5000)]:
+        part = movmodel.simulate_tracks(0., starts[lo:hi], (rows, cols), 1, 1., upd, pot,
+                                        seed=30, track_id_base=lo, hist=parts)
+        parts = part.hist
+        lens.append(part.lengths)
+    assert torch.equal(torch.cat(lens), whole.lengths)
+    assert torch.equal(parts, whole.hist)
+    assert int(whole.hist.sum()) == int(whole.lengths.sum())
+    again = movmodel.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=30,
+                                     use_table=True)
+    assert torch.equal(again.hist, whole.hist) and torch.equal(again.ends, whole.ends)
