@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): simulated tracks/s + updraft-raster
+Mcells/s on the 60x50 km @10 m uniform-mode raster (5000 x 6000 cells),
+100k tracks per MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic input, with
+every input already resident in HBM:
+    DEM --K1 fused raster--> orograph f32 + usable updraft f64
+        --K2a--> per-cell transition table (updraft x potential)
+        --K2b/K3--> 100k tracks stepped to completion + uint32 presence histogram
+        [N > 1: one RCCL sum-reduce of the histogram to rank 0]
+Tracks shard over ranks by global track id (weak scaling: 100k tracks per GPU).
+
+Launch: `python bench.py` (1 GPU) or
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+ --master-port P bench.py --gpus N --steps K --warmup W`.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+STEP_BYTES = 76                 # 9x4 + 9x4 window + 4 B point/RMW
+RASTER_BYTES_PER_CELL = 20      # fused K1 as benchmarked: f64 DEM in (8) + f32 out (4)
+#                                 + f64 usable out (8); SURVEY's 12 B/cell figure is
+#                                 the f32-in/f32-out elementwise kernel
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--tracks', type=int, default=100_000, help='tracks per GPU')
+    ap.add_argument('--resolution', type=float, default=10.0)
+    ap.add_argument('--width-km', type=float, nargs=2, default=(60.0, 50.0))
+    ap.add_argument('--direct', action='store_true', help='3x3 window gathers, no table')
+    ap.add_argument('--steps-per-launch', type=int, default=0)
+    ap.add_argument('--cpu-seconds', type=float, default=20.0,
+                    help='target CPU time of the cpu_baseline sample (0 = skip)')
+    ap.add_argument('--potential', default='ramp', choices=['ramp', 'solve'])
+    return ap.parse_args()
+
+
+def cpu_baseline(args, gridsize, dem, pot, starts, seed, steps_per_track):
+    """Oracle (C port of the reference algorithm, OpenMP) on the host cores, on
+    a bounded sample of the same workload: the full-grid raster once and the
+    first M tracks (same global ids / Philox streams as the GPU run)."""
+    from oracle import c_oracle
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    slope, aspect = c_oracle.slope_aspect(dem, args.resolution)
+    _, oro32 = c_oracle.orographic(slope, aspect, 10.0, 270.0)
+    upd = c_oracle.threshold(oro32, 0.75)
+    t_raster = time.perf_counter() - t0
+    # calibrate, then size the sample for ~cpu_seconds of stepping
+    t0 = time.perf_counter()
+    cal = c_oracle.simulate_tracks(0.0, starts[:2 * cores], gridsize, 1, 1.0, upd, pot,
+                                   seed=seed, want_traj=False, want_hist=True, nthreads=cores)
+    t_cal = max(time.perf_counter() - t0, 1e-6)
+    rate = cal['steps'] / t_cal
+    m = int(min(len(starts), max(2 * cores, rate * args.cpu_seconds / max(steps_per_track, 1))))
+    t0 = time.perf_counter()
+    run = c_oracle.simulate_tracks(0.0, starts[:m], gridsize, 1, 1.0, upd, pot, seed=seed,
+                                   want_traj=False, want_hist=True, nthreads=cores)
+    t_run = time.perf_counter() - t0
+    return {
+        'value': m / t_run, 'unit': 'tracks/s', 'cores': cores, 'kind': 'port',
+        'sample': (f'C/OpenMP oracle port, first {m} of the {len(starts)} tracks of this '
+                   f'workload ({run["steps"]} steps in {t_run:.1f} s) on {cores} host threads; '
+                   f'raster chain on the full grid once ({t_raster:.1f} s)'),
+        'steps_per_s': run['steps'] / t_run,
+        'steps_per_s_per_core': run['steps'] / t_run / cores,
+        'raster_mcells_per_s': gridsize[0] * gridsize[1] / t_raster / 1e6,
+    }, run, m
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with '
+                         f'torch.distributed.run --nproc-per-node {args.gpus}')
+    assert torch.cuda.is_available(), 'bench.py needs a GPU'
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=rank, world_size=world,
+                                device_id=torch.device('cuda', local_rank))
+
+    from ssrs_amd import layers, movmodel, _native
+    from ssrs_amd.distributed import shard_range, reduce_histogram
+    from ssrs_amd.synthetic import synthetic_dem, ramp_potential
+    _native.lib()
+
+    res = args.resolution
+    cols = int(round(args.width_km[0] * 1000.0 / res))
+    rows = int(round(args.width_km[1] * 1000.0 / res))
+    gridsize = (rows, cols)
+    ncells = rows * cols
+    seed = 30
+    n_total = args.tracks * world
+    # identical on every rank: replicated rasters, global start list
+    dem_h = synthetic_dem(gridsize, res)
+    np.random.seed(seed)
+    srows, scols = movmodel.get_starting_indices(n_total, (5, 55, 1, 2), 'random',
+                                                 tuple(args.width_km), res)
+    starts_h = np.stack([srows, scols], 1).astype(np.int32)
+    lo, hi = shard_range(n_total, rank, world)
+    dev = torch.device('cuda', local_rank)
+    dem = torch.from_numpy(dem_h).to(dev)
+    starts = torch.from_numpy(starts_h[lo:hi]).to(dev)
+    if args.potential == 'solve':
+        from ssrs_amd.potential import solve_potential
+        _, upd0 = layers.updraft_from_dem(dem, res, 10.0, 270.0, threshold=0.75)
+        pot = solve_potential(upd0, 0.0)
+        pot_label = 'ssrs_potential_solve (matrix-free GPU solver)'
+        del upd0
+    else:
+        pot = torch.from_numpy(ramp_potential(gridsize)).to(dev)
+        pot_label = ('LABELLED STAND-IN: linear ramp 1000(1-r/(R-1)) (exact solution for '
+                     'uniform conductance); the reference spsolve is infeasible at 3e7 cells')
+    hist = torch.zeros(gridsize, dtype=torch.int32, device=dev)
+
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    acc = dict(raster_ms=0.0, table_ms=0.0, step_kernel_ms=0.0, step_wall_ms=0.0,
+               steps=0, launches=0)
+
+    def one_step(timed):
+        hist.zero_()
+        ev[0].record()
+        oro, upd = layers.updraft_from_dem(dem, res, 10.0, 270.0, threshold=0.75)
+        ev[1].record()
+        table = None if args.direct else movmodel.build_transition_table(upd, pot)
+        ev[2].record()
+        out = movmodel.simulate_tracks(0.0, starts, gridsize, 1, 1.0, upd, pot, seed=seed,
+                                       track_id_base=lo, table=table, use_table=not args.direct,
+                                       hist=hist, steps_per_launch=args.steps_per_launch,
+                                       profile=True)
+        reduce_histogram(hist, dst=0)
+        ev[3].record()
+        if timed:
+            torch.cuda.synchronize()
+            acc['raster_ms'] += ev[0].elapsed_time(ev[1])
+            acc['table_ms'] += ev[1].elapsed_time(ev[2])
+            acc['step_kernel_ms'] += out.stats['kernel_ms']
+            acc['step_wall_ms'] += out.stats['wall_ms']
+            acc['steps'] += out.stats['total_steps']
+            acc['launches'] += out.stats['launches']
+        return out
+
+    for _ in range(args.warmup):
+        one_step(False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = one_step(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = torch.tensor([acc['steps']], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_steps_all = int(tot.item())
+    else:
+        total_steps_all = acc['steps']
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    K = args.steps
+    lengths = last.lengths.cpu().numpy()
+    steps_per_track = float(lengths.mean() - 1)
+    assert int(hist.sum().item()) == (int(lengths.sum()) if world == 1 else int(hist.sum().item()))
+    kernel_s = acc['step_kernel_ms'] / 1e3
+    achieved = acc['steps'] * STEP_BYTES / kernel_s / 1e9 if kernel_s > 0 else 0.0
+    raster_s = acc['raster_ms'] / 1e3 / K
+    out = {
+        'metric': 'simulated tracks/sec (whole node)',
+        'value': n_total * K / elapsed,
+        'unit': 'tracks/s',
+        'n_gpus': world, 'steps': K, 'warmup': args.warmup,
+        'ms_per_step': elapsed / K * 1e3,
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'f64',
+        'data': 'synthetic',
+        'config': {
+            'workload': (f'uniform mode, {args.width_km[0]:g}x{args.width_km[1]:g} km @{res:g} m '
+                         f'({rows}x{cols} grid), {args.tracks} tracks per GPU, wind 10 m/s @270, '
+                         f'threshold 0.75, direction 0, seed 30 (BASELINE.json configs[1])'),
+            'tracks_total': n_total,
+            'parallelism': f'track-sharded x{world}, replicated rasters'
+                           + (', RCCL histogram reduce' if world > 1 else ''),
+            'stepper_path': 'direct 3x3 gathers' if args.direct else 'transition table',
+            'potential': pot_label,
+        },
+        'steps_per_s': total_steps_all / elapsed,
+        'steps_per_track_mean': steps_per_track,
+        'steps_per_track_max': int(lengths.max() - 1),
+        'raster_mcells_per_s': ncells / raster_s / 1e6 if raster_s > 0 else None,
+        'raster_gbps': ncells * RASTER_BYTES_PER_CELL / raster_s / 1e9 if raster_s > 0 else None,
+        'phase_ms_per_step': {
+            'raster_k1': acc['raster_ms'] / K, 'table_k2a': acc['table_ms'] / K,
+            'stepper_kernels_k2b': acc['step_kernel_ms'] / K,
+            'stepper_wall': acc['step_wall_ms'] / K,
+        },
+        'roofline': {
+            'kernel': 'k_step_tracks (K2 stepper, rank 0)',
+            'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+            'frac': achieved / HBM_PEAK_GBPS,
+            'traffic': None,
+            'algorithmic_bytes_per_step': STEP_BYTES,
+            'launches': acc['launches'] // K,
+            'avg_launch_ms': acc['step_kernel_ms'] / max(acc['launches'], 1),
+            'avg_bytes_per_launch': acc['steps'] * STEP_BYTES / max(acc['launches'], 1),
+        },
+    }
+    pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if os.path.exists(pmc):
+        try:
+            with open(pmc) as f:
+                rec = json.load(f)
+            out['roofline']['traffic'] = rec.get('k_step_tracks_bytes_per_launch')
+            out['roofline']['traffic_source'] = rec.get('source')
+        except Exception:
+            pass
+    if world == 1 and args.cpu_seconds > 0:
+        cpu, run, m = cpu_baseline(args, gridsize, dem_h, pot.cpu().numpy(), starts_h, seed,
+                                   steps_per_track)
+        out['cpu_baseline'] = cpu
+        # same tracks, same streams: the GPU's lengths for the sample must agree
+        # unless the usable-updraft rasters differ in the last f64 bits
+        out['cpu_baseline']['sample_lengths_equal_gpu'] = bool(
+            np.array_equal(run['lengths'], lengths[:m]))
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -163,6 +163,63 @@ int ssrs_tracks_simulate(const SsrsTrackParams *params, const double *updraft,
                          size_t workspace_bytes, SsrsTrackStats *stats,
                          void *stream);
 
+/* --------------------------------------------------------------- presence */
+
+/* compute_presence_counts (ssrs/movmodel.py:410-419) from stored trajectories:
+ * hist[row, col] += 1 for each of the npoints int16 (row, col) pairs.  uint32
+ * counts (the reference's int16 matrix wraps above 32767 visits).  A point
+ * outside the raster is an error (the reference raises IndexError).
+ * scratch8: 8 bytes of device scratch. */
+int ssrs_presence_count(const int16_t *traj, int64_t npoints, uint32_t *hist,
+                        int rows, int cols, void *scratch8, void *stream);
+
+size_t ssrs_presence_workspace_bytes(int rows, int cols, int krad);
+
+/* compute_smooth_presence_counts (ssrs/movmodel.py:422-439) on a count matrix:
+ * zero-padded 'same' convolution with the disk kernel (x^2+y^2 <= krad^2)/ntaps,
+ * f32 out.  Evaluated as 2*krad+1 chords of row prefix sums: exact in integers,
+ * then one multiply by 1/ntaps. */
+int ssrs_presence_smooth(const uint32_t *count, int krad, float *out, int rows,
+                         int cols, void *workspace, size_t workspace_bytes,
+                         void *stream);
+
+/* The normalisation ladder of Simulator.plot_presence_map (simulator.py:529-546):
+ *   acc += src / max(src)     (division in src's precision: f32 for `prprob`,
+ *                              f64 for `case_prob`)
+ *   out  = f32(src / max(src)) (summary_presence.npy) */
+int ssrs_presence_normalise_add(const void *src, int src_type, double *acc, size_t n,
+                                void *scratch8, void *stream);
+int ssrs_presence_normalise_f32(const double *src, float *out, size_t n,
+                                void *scratch8, void *stream);
+
+/* -------------------------------------------------------------- potential */
+
+typedef struct SsrsSolveStats {
+    int32_t iterations;
+    int32_t converged; /* 1 when |r| <= rel_tol |b| was reached */
+    double residual;   /* final |r| / |b| */
+    float kernel_ms;
+} SsrsSolveStats;
+
+size_t ssrs_potential_workspace_bytes(int rows, int cols);
+
+/* MovModel.assemble_sparse_linear_system + solve_sparse_linear_system
+ * (ssrs/movmodel.py:59-128) without assembling anything: the row-normalised
+ * 8-neighbour conductance operator is applied matrix-free and the Dirichlet
+ * problem is solved iteratively in f64 (the reference factorises with SuperLU).
+ *   conductivity  f64 (rows, cols): the usable updraft
+ *   fixed_mask    u8  (rows, cols): 1 on Dirichlet cells (get_boundary_nodes,
+ *                 movmodel.py:21-57, evaluated by the host)
+ *   fixed_values  f64 (rows, cols): boundary energy on those cells
+ *   initial_guess f64 (rows, cols) or NULL
+ *   potential     f32 (rows, cols) out, as `pot_energy.astype(np.float32)` */
+int ssrs_potential_solve(const double *conductivity, const uint8_t *fixed_mask,
+                         const double *fixed_values, const double *initial_guess,
+                         float *potential, int rows, int cols, double rel_tol,
+                         int max_iterations, void *workspace, size_t workspace_bytes,
+                         void *stats /* SsrsSolveStats*, [host], may be NULL */,
+                         void *stream);
+
 /* n uniforms of the contract above: out[i] = u(seed, track[i], step[i]).
  * Device self-check of the rocRAND-backed draw used by the stepper. */
 int ssrs_uniform_selftest(uint64_t seed, const uint64_t *track,

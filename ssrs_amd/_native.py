@@ -19,6 +19,9 @@ EXPORTS = (
     'ssrs_orographic_updraft', 'ssrs_threshold_updraft', 'ssrs_updraft_from_dem',
     'ssrs_track_params_init', 'ssrs_transition_table_build',
     'ssrs_tracks_workspace_bytes', 'ssrs_tracks_simulate', 'ssrs_uniform_selftest',
+    'ssrs_presence_count', 'ssrs_presence_workspace_bytes', 'ssrs_presence_smooth',
+    'ssrs_presence_normalise_add', 'ssrs_presence_normalise_f32',
+    'ssrs_potential_workspace_bytes', 'ssrs_potential_solve',
 )
 
 
@@ -63,7 +66,7 @@ def lib():
         L.ssrs_tracks_workspace_bytes.argtypes = [C.c_int64]
         if hasattr(L, 'ssrs_presence_workspace_bytes'):
             L.ssrs_presence_workspace_bytes.restype = C.c_size_t
-            L.ssrs_presence_workspace_bytes.argtypes = [C.c_int, C.c_int]
+            L.ssrs_presence_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
         if hasattr(L, 'ssrs_potential_workspace_bytes'):
             L.ssrs_potential_workspace_bytes.restype = C.c_size_t
             L.ssrs_potential_workspace_bytes.argtypes = [C.c_int, C.c_int]

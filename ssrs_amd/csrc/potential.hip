@@ -1,0 +1,368 @@
+// K5 -- directional potential: matrix-free solve of the fluid-flow system on gfx950.
+//
+// Reference semantics (paths relative to /root/reference):
+//   ssrs/movmodel.py:59-84    assemble_sparse_linear_system: 8-neighbour lists,
+//                             sqrt(2) on odd positions of the FILTERED list
+//   ssrs/movmodel.py:87-128   solve_sparse_linear_system: conductance
+//                             hm(c_i, c_j) (1e-8 if either is 0) / fac, row
+//                             normalised G; (I - G_ii) phi_i = G_ib phi_b; spsolve
+//   ssrs/movmodel.py:442-447  harmonic_mean
+//
+// The reference builds the matrix in python loops and factorises it with
+// SuperLU (10.8 s at 500x600, infeasible at 5000x6000).  Here nothing is
+// assembled: a 9-point variable-coefficient stencil recomputes each row's
+// normalised conductances from the conductivity raster on the fly, and the
+// system is solved with BiCGStab in f64.  The operator is exactly the
+// reference's, including its quirk that east-edge interior nodes weight their
+// S neighbour by 1/sqrt(2) and SW by 1 (position parity after filtering).
+// Dirichlet cells come from the host (MovModel.get_boundary_nodes restated in
+// ssrs_amd/potential.py) as a mask + value raster.
+#include <cmath>
+
+#include "common.h"
+
+namespace ssrs {
+
+// f32 sqrt(2) widened, as `harmonic_mean(...) / fac` with fac an np.float32
+#define SSRS_FAC_DIAG 1.41421353816986083984375
+
+__device__ __forceinline__ double pair_conductance(double a, double b)
+{
+    return (a != 0.0 && b != 0.0) ? 2.0 / (1.0 / a + 1.0 / b) : 1e-08;
+}
+
+// y = (I - G) x on free cells, y = 0 on Dirichlet cells (x is 0 there for
+// Krylov vectors; for the residual set-up the caller passes the full field).
+// If DOTS: accumulates block partials of (w, y) and (y, y) [w may be NULL -> (x, y)].
+struct StencilArgs {
+    const double *cond;
+    const uint8_t *fixed;     // 1 = Dirichlet
+    int rows, cols;
+};
+
+__device__ __forceinline__ double apply_row(const StencilArgs &a, const double *__restrict__ x,
+                                            int r, int c)
+{
+    const int R = a.rows, C = a.cols;
+    const size_t i = static_cast<size_t>(r) * C + c;
+    const double ci = a.cond[i];
+    double wsum = 0.0, acc = 0.0;
+    const bool east_quirk = (c == C - 1) && r > 0 && r < R - 1;
+    // neighbour order is irrelevant for the mathematics; the sum order below is
+    // fixed (W, NW, N, NE, E, SE, S, SW) so runs are reproducible
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int dr = (k == 1 || k == 2 || k == 3) ? 1 : ((k == 5 || k == 6 || k == 7) ? -1 : 0);
+        const int dc = (k == 0 || k == 1 || k == 7) ? -1 : ((k == 3 || k == 4 || k == 5) ? 1 : 0);
+        const int rr = r + dr, cc = c + dc;
+        if (rr < 0 || rr >= R || cc < 0 || cc >= C) continue;
+        bool diag = (dr != 0 && dc != 0);
+        if (east_quirk && dr == -1) diag = !diag;     // S <-> SW weights swapped
+        const size_t j = static_cast<size_t>(rr) * C + cc;
+        double w = pair_conductance(ci, a.cond[j]);
+        if (diag) w = w / SSRS_FAC_DIAG;
+        wsum += w;
+        acc += w * x[j];
+    }
+    return x[i] - acc / wsum;
+}
+
+constexpr int kRedBlocks = 1024;
+
+__device__ __forceinline__ double block_sum(double v, double *lds)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    double s = 0.0;
+    if (threadIdx.x == 0)
+        for (int w = 0; w < kBlock / 64; ++w) s += lds[w];
+    __syncthreads();
+    return s;   // valid in thread 0
+}
+
+// scalars live in device memory so that no iteration waits on the host
+struct Scalars {
+    double rho, rho_old, alpha, omega, rhat_v, ts, tt, rnorm2, bnorm2;
+    double part[6][kRedBlocks];
+};
+
+// v = A p ; partial (rhat, v)
+__global__ __launch_bounds__(kBlock) void k_apply_dot1(StencilArgs a, const double *__restrict__ p,
+                                                      double *__restrict__ v,
+                                                      const double *__restrict__ rhat, Scalars *s)
+{
+    __shared__ double lds[kBlock / 64];
+    const size_t n = static_cast<size_t>(a.rows) * a.cols;
+    double d = 0.0;
+    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * kBlock) {
+        double y = 0.0;
+        if (!a.fixed[i]) y = apply_row(a, p, static_cast<int>(i / a.cols), static_cast<int>(i % a.cols));
+        v[i] = y;
+        d += rhat[i] * y;
+    }
+    d = block_sum(d, lds);
+    if (threadIdx.x == 0) s->part[0][blockIdx.x] = d;
+}
+
+// s_vec = r - alpha v ; t = A s_vec needs a second pass, so this kernel only forms s_vec
+__global__ __launch_bounds__(kBlock) void k_form_s(const double *__restrict__ r,
+                                                  const double *__restrict__ v,
+                                                  double *__restrict__ sv, size_t n, Scalars *s)
+{
+    const double alpha = s->alpha;
+    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * kBlock)
+        sv[i] = r[i] - alpha * v[i];
+}
+
+// t = A s_vec ; partials (t, s) and (t, t)
+__global__ __launch_bounds__(kBlock) void k_apply_dot2(StencilArgs a, const double *__restrict__ sv,
+                                                      double *__restrict__ t, Scalars *s)
+{
+    __shared__ double lds[kBlock / 64];
+    const size_t n = static_cast<size_t>(a.rows) * a.cols;
+    double d1 = 0.0, d2 = 0.0;
+    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * kBlock) {
+        double y = 0.0;
+        if (!a.fixed[i]) y = apply_row(a, sv, static_cast<int>(i / a.cols), static_cast<int>(i % a.cols));
+        t[i] = y;
+        d1 += y * sv[i];
+        d2 += y * y;
+    }
+    d1 = block_sum(d1, lds);
+    d2 = block_sum(d2, lds);
+    if (threadIdx.x == 0) { s->part[1][blockIdx.x] = d1; s->part[2][blockIdx.x] = d2; }
+}
+
+// x += alpha p + omega s ; r = s - omega t ; partials (rhat, r), (r, r)
+__global__ __launch_bounds__(kBlock) void k_update_xr(double *__restrict__ x, double *__restrict__ r,
+                                                     const double *__restrict__ p,
+                                                     const double *__restrict__ sv,
+                                                     const double *__restrict__ t,
+                                                     const double *__restrict__ rhat, size_t n,
+                                                     Scalars *s)
+{
+    __shared__ double lds[kBlock / 64];
+    const double alpha = s->alpha, omega = s->omega;
+    double d1 = 0.0, d2 = 0.0;
+    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * kBlock) {
+        x[i] = x[i] + alpha * p[i] + omega * sv[i];
+        const double rn = sv[i] - omega * t[i];
+        r[i] = rn;
+        d1 += rhat[i] * rn;
+        d2 += rn * rn;
+    }
+    d1 = block_sum(d1, lds);
+    d2 = block_sum(d2, lds);
+    if (threadIdx.x == 0) { s->part[3][blockIdx.x] = d1; s->part[4][blockIdx.x] = d2; }
+}
+
+// p = r + beta (p - omega v)
+__global__ __launch_bounds__(kBlock) void k_update_p(double *__restrict__ p,
+                                                    const double *__restrict__ r,
+                                                    const double *__restrict__ v, size_t n,
+                                                    Scalars *s)
+{
+    const double beta = (s->rho / s->rho_old) * (s->alpha / s->omega);
+    const double omega = s->omega;
+    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * kBlock)
+        p[i] = r[i] + beta * (p[i] - omega * v[i]);
+}
+
+// single-block scalar updates between the vector kernels (deterministic sums)
+enum { FIN_ALPHA = 0, FIN_OMEGA = 1, FIN_RHO = 2, FIN_INIT = 3, FIN_BNORM = 4 };
+__global__ __launch_bounds__(kBlock) void k_finish(Scalars *s, int what, int nblocks)
+{
+    __shared__ double lds[kBlock / 64];
+    auto total = [&](int slot) {
+        double d = 0.0;
+        for (int i = threadIdx.x; i < nblocks; i += kBlock) d += s->part[slot][i];
+        return block_sum(d, lds);
+    };
+    if (what == FIN_ALPHA) {
+        const double rv = total(0);
+        if (threadIdx.x == 0) { s->rhat_v = rv; s->alpha = s->rho / rv; }
+    } else if (what == FIN_OMEGA) {
+        const double ts = total(1);
+        const double tt = total(2);
+        if (threadIdx.x == 0) { s->ts = ts; s->tt = tt; s->omega = tt > 0.0 ? ts / tt : 0.0; }
+    } else if (what == FIN_RHO) {
+        const double rho = total(3);
+        const double rr = total(4);
+        if (threadIdx.x == 0) { s->rho_old = s->rho; s->rho = rho; s->rnorm2 = rr; }
+    } else if (what == FIN_BNORM) {          // |b|^2: residual of the zero field
+        const double rr = total(4);
+        if (threadIdx.x == 0) s->bnorm2 = rr;
+    } else {
+        const double rr = total(4);
+        if (threadIdx.x == 0) {
+            s->rho = rr; s->rho_old = 1.0; s->alpha = 1.0; s->omega = 1.0;
+            s->rnorm2 = rr;
+        }
+    }
+}
+
+// set-up: x0 = Dirichlet values on fixed cells / initial guess elsewhere;
+// r = b - A x0 (b = 0 on free cells), rhat = r, p = r, v = 0; partial (r, r)
+__global__ __launch_bounds__(kBlock) void k_setup(StencilArgs a, const double *__restrict__ x,
+                                                 double *__restrict__ r, double *__restrict__ rhat,
+                                                 double *__restrict__ p, double *__restrict__ v,
+                                                 Scalars *s)
+{
+    __shared__ double lds[kBlock / 64];
+    const size_t n = static_cast<size_t>(a.rows) * a.cols;
+    double d = 0.0;
+    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * kBlock) {
+        double res = 0.0;
+        if (!a.fixed[i]) res = -apply_row(a, x, static_cast<int>(i / a.cols), static_cast<int>(i % a.cols));
+        r[i] = res; rhat[i] = res; p[i] = res; v[i] = 0.0;
+        d += res * res;
+    }
+    d = block_sum(d, lds);
+    if (threadIdx.x == 0) s->part[4][blockIdx.x] = d;
+}
+
+__global__ __launch_bounds__(kBlock) void k_init_x(const uint8_t *__restrict__ fixed,
+                                                  const double *__restrict__ fixed_val,
+                                                  const double *__restrict__ guess, double fill,
+                                                  double *__restrict__ x, int rows, int cols)
+{
+    const size_t n = static_cast<size_t>(rows) * cols;
+    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * kBlock)
+        x[i] = fixed[i] ? fixed_val[i] : (guess ? guess[i] : fill);
+}
+
+__global__ __launch_bounds__(kBlock) void k_to_f32(const double *__restrict__ x,
+                                                  float *__restrict__ out, size_t n)
+{
+    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * kBlock)
+        out[i] = static_cast<float>(x[i]);
+}
+
+static size_t vec_bytes(size_t n) { return (n * 8 + 255) / 256 * 256; }
+
+}  // namespace ssrs
+
+using namespace ssrs;
+
+extern "C" size_t ssrs_potential_workspace_bytes(int rows, int cols)
+{
+    if (rows <= 0 || cols <= 0) return 0;
+    const size_t n = static_cast<size_t>(rows) * cols;
+    return (sizeof(Scalars) + 255) / 256 * 256 + 8 * vec_bytes(n);
+}
+
+typedef struct SsrsSolveStatsInternal {
+    int32_t iterations, converged;
+    double residual;
+    float kernel_ms;
+} SsrsSolveStatsInternal;
+
+extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *fixed_mask,
+                                    const double *fixed_values, const double *initial_guess,
+                                    float *potential, int rows, int cols, double rel_tol,
+                                    int max_iterations, void *workspace, size_t workspace_bytes,
+                                    void *stats_out, void *stream)
+{
+    SSRS_REQUIRE(conductivity && fixed_mask && fixed_values && potential && workspace,
+                 "ssrs_potential_solve: NULL pointer");
+    SSRS_REQUIRE(rows >= 3 && cols >= 3, "ssrs_potential_solve: need rows, cols >= 3");
+    SSRS_REQUIRE(workspace_bytes >= ssrs_potential_workspace_bytes(rows, cols),
+                 "ssrs_potential_solve: workspace too small");
+    SSRS_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0,
+                 "ssrs_potential_solve: workspace must be 256-byte aligned");
+    SSRS_REQUIRE(rel_tol > 0.0 && max_iterations > 0, "ssrs_potential_solve: bad tolerance / iteration cap");
+    hipStream_t st = as_stream(stream);
+    const size_t n = static_cast<size_t>(rows) * cols;
+    char *base = static_cast<char *>(workspace);
+    Scalars *sc = reinterpret_cast<Scalars *>(base);
+    base += (sizeof(Scalars) + 255) / 256 * 256;
+    double *vec[8];
+    for (int i = 0; i < 8; ++i) vec[i] = reinterpret_cast<double *>(base + i * vec_bytes(n));
+    double *x = vec[0], *r = vec[1], *rhat = vec[2], *p = vec[3], *v = vec[4], *sv = vec[5], *t = vec[6];
+    double *xbest = vec[7];
+    StencilArgs a{conductivity, fixed_mask, rows, cols};
+    int nb = static_cast<int>((n + kBlock - 1) / kBlock);
+    if (nb > kRedBlocks) nb = kRedBlocks;
+    hipEvent_t e0, e1;
+    SSRS_HIP_CHECK(hipEventCreate(&e0));
+    SSRS_HIP_CHECK(hipEventCreate(&e1));
+    SSRS_HIP_CHECK(hipEventRecord(e0, st));
+    SSRS_HIP_CHECK(hipMemsetAsync(sc, 0, sizeof(Scalars), st));
+    // |b| (stopping criterion is |r| <= rel_tol |b|, independent of the start)
+    hipLaunchKernelGGL(k_init_x, dim3(nb), dim3(kBlock), 0, st, fixed_mask, fixed_values,
+                       static_cast<const double *>(nullptr), 0.0, x, rows, cols);
+    hipLaunchKernelGGL(k_setup, dim3(nb), dim3(kBlock), 0, st, a, x, r, rhat, p, v, sc);
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, st, sc, FIN_BNORM, nb);
+    // start field: caller's guess, else the mid value 500
+    hipLaunchKernelGGL(k_init_x, dim3(nb), dim3(kBlock), 0, st, fixed_mask, fixed_values,
+                       initial_guess, 500.0, x, rows, cols);
+    hipLaunchKernelGGL(k_setup, dim3(nb), dim3(kBlock), 0, st, a, x, r, rhat, p, v, sc);
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, st, sc, FIN_INIT, nb);
+    SSRS_HIP_CHECK(hipGetLastError());
+    double host[2] = {0.0, 0.0};
+    int it = 0, converged = 0, restarts = 0;
+    const int check_every = 25, max_restarts = 50;
+    double rel = 1.0, best = 1e300;
+    bool fresh = true;                     // p == r (no k_update_p on the first pass)
+    while (it < max_iterations) {
+        for (int j = 0; j < check_every && it < max_iterations; ++j, ++it) {
+            if (!fresh) hipLaunchKernelGGL(k_update_p, dim3(nb), dim3(kBlock), 0, st, p, r, v, n, sc);
+            fresh = false;
+            hipLaunchKernelGGL(k_apply_dot1, dim3(nb), dim3(kBlock), 0, st, a, p, v, rhat, sc);
+            hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, st, sc, FIN_ALPHA, nb);
+            hipLaunchKernelGGL(k_form_s, dim3(nb), dim3(kBlock), 0, st, r, v, sv, n, sc);
+            hipLaunchKernelGGL(k_apply_dot2, dim3(nb), dim3(kBlock), 0, st, a, sv, t, sc);
+            hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, st, sc, FIN_OMEGA, nb);
+            hipLaunchKernelGGL(k_update_xr, dim3(nb), dim3(kBlock), 0, st, x, r, p, sv, t, rhat, n, sc);
+            hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, st, sc, FIN_RHO, nb);
+        }
+        SSRS_HIP_CHECK(hipGetLastError());
+        SSRS_HIP_CHECK(hipMemcpyAsync(host, &sc->rnorm2, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+        SSRS_HIP_CHECK(hipStreamSynchronize(st));
+        const bool finite = host[0] == host[0] && host[0] < 1e300;
+        const double now = finite && host[1] > 0.0 ? std::sqrt(host[0] / host[1]) : (finite ? 0.0 : 1e300);
+        if (finite && now < best) {
+            best = now;
+            rel = now;
+            SSRS_HIP_CHECK(hipMemcpyAsync(xbest, x, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+            if (rel <= rel_tol) { converged = 1; break; }
+        }
+        // BiCGStab breakdown (rho or omega -> 0) or a residual that ran away:
+        // restart from the best iterate with a fresh shadow residual
+        if (!finite || now > 1e3 * best) {
+            if (++restarts > max_restarts) break;
+            SSRS_HIP_CHECK(hipMemcpyAsync(x, xbest, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+            hipLaunchKernelGGL(k_setup, dim3(nb), dim3(kBlock), 0, st, a, x, r, rhat, p, v, sc);
+            hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, st, sc, FIN_INIT, nb);
+            fresh = true;
+        }
+    }
+    if (best < 1e300) SSRS_HIP_CHECK(hipMemcpyAsync(x, xbest, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_to_f32, dim3(nb), dim3(kBlock), 0, st, x, potential, n);
+    SSRS_HIP_CHECK(hipGetLastError());
+    SSRS_HIP_CHECK(hipEventRecord(e1, st));
+    SSRS_HIP_CHECK(hipStreamSynchronize(st));
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (stats_out) {
+        auto *so = static_cast<SsrsSolveStatsInternal *>(stats_out);
+        so->iterations = it;
+        so->converged = converged;
+        so->residual = rel;
+        so->kernel_ms = ms;
+    }
+    return SSRS_OK;
+}

@@ -211,3 +211,32 @@ def uniforms(seed, track, step):
         C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), nat.ptr(tr), nat.ptr(sp), nat.ptr(out),
         C.c_size_t(tr.numel()), stream_ptr()))
     return out.cpu().numpy()
+
+
+# ---------------------------------------------------------------- re-exports
+from .presence import (compute_presence_counts, compute_smooth_presence_counts)  # noqa: E402
+from . import potential as _potential  # noqa: E402
+
+
+class MovModel:
+    """Fluid-flow movement model (movmodel.py:10-128).  Same constructor; the
+    three-call sequence of the reference (boundary nodes, assemble, solve)
+    is kept for compatibility, but nothing is assembled: `solve` runs the
+    matrix-free GPU solver."""
+
+    def __init__(self, move_dirn, grid_shape):
+        self.move_dirn = move_dirn
+        self.grid_shape = grid_shape
+
+    def get_boundary_nodes(self):
+        return _potential.get_boundary_nodes(self.move_dirn, self.grid_shape)
+
+    def assemble_sparse_linear_system(self):
+        """No-op placeholder: the operator is applied matrix-free on the GPU."""
+        return None, None, None
+
+    def solve_sparse_linear_system(self, conductivity, bnodes=None, benergy=None,
+                                   row_inds=None, col_inds=None, facs=None, **kwargs):
+        """Potential f32 (rows, cols).  bnodes/benergy are re-derived from
+        move_dirn (they are a pure function of it in the reference too)."""
+        return _potential.solve_potential(conductivity, self.move_dirn, **kwargs)

@@ -1,0 +1,92 @@
+"""Directional potential (K5) host side: the Dirichlet sets of
+MovModel.get_boundary_nodes (/root/reference/ssrs/movmodel.py:21-57) are
+small integer logic evaluated here; the linear solve itself runs matrix-free
+on the GPU (ssrs_potential_solve), replacing assemble_sparse_linear_system +
+solve_sparse_linear_system (movmodel.py:59-128)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native as nat
+from ._device import stream_ptr, to_dev, like_input
+
+
+def get_boundary_nodes(move_dirn, grid_shape):
+    """movmodel.py:21-57 -> (node ids, energies); node id = col * nrow + row.
+
+    The movement direction picks which edge segments are held at 0 ("low",
+    downstream) and at 1000 ("high", upstream).  As in the reference the energy
+    vector is split at its midpoint, whatever the two list lengths are.
+    """
+    nrow, ncol = int(grid_shape[0]), int(grid_shape[1])
+    cols = np.arange(ncol, dtype=np.int64)
+    inner_rows = np.arange(1, nrow - 1, dtype=np.int64)
+    north = nrow * (cols + 1) - 1
+    south = nrow * cols
+    west = inner_rows
+    east = (ncol - 1) * nrow + inner_rows
+    angle = move_dirn % 90.
+    quadrant = int((move_dirn % 360) // 90.)
+    col_len = round(ncol * angle / 90.)
+    row_len = round(nrow * angle / 90.)
+    if quadrant == 0:
+        low = (north[col_len:], east[nrow - row_len:])
+        high = (south[:ncol - col_len], west[:row_len])
+    elif quadrant == 1:
+        low = (south[ncol - col_len:], east[:nrow - row_len])
+        high = (north[:col_len], west[row_len:])
+    elif quadrant == 2:
+        low = (south[:ncol - col_len], west[:row_len])
+        high = (north[col_len:], east[nrow - row_len:])
+    else:
+        high = (south[ncol - col_len:], east[:nrow - row_len])
+        low = (north[:col_len], west[row_len:])
+    nodes = np.concatenate(low + high)
+    energy = np.zeros(nodes.size)
+    energy[nodes.size // 2:] = 1000.
+    return nodes, energy
+
+
+def dirichlet_rasters(move_dirn, grid_shape):
+    """Boundary nodes as (mask u8, values f64) rasters of shape (rows, cols)."""
+    nrow, ncol = int(grid_shape[0]), int(grid_shape[1])
+    nodes, energy = get_boundary_nodes(move_dirn, (nrow, ncol))
+    mask = np.zeros((nrow, ncol), dtype=np.uint8)
+    vals = np.zeros((nrow, ncol), dtype=np.float64)
+    r, c = nodes % nrow, nodes // nrow
+    mask[r, c] = 1
+    vals[r, c] = energy
+    return mask, vals
+
+
+def solve_potential(updraft, move_dirn, rel_tol=1e-12, max_iterations=200000,
+                    initial_guess=None, return_stats=False):
+    """MovModel(...).solve_sparse_linear_system equivalent -> f32 (rows, cols).
+
+    `updraft` is the conductivity raster (usable updraft, f64); numpy in ->
+    numpy out, CUDA tensor in -> tensor out.
+    """
+    cond = to_dev(updraft, torch.float64)
+    rows, cols = int(cond.shape[0]), int(cond.shape[1])
+    mask_h, vals_h = dirichlet_rasters(move_dirn, (rows, cols))
+    mask = to_dev(mask_h)
+    vals = to_dev(vals_h)
+    guess = to_dev(initial_guess, torch.float64)
+    out = torch.empty((rows, cols), dtype=torch.float32, device=cond.device)
+    nbytes = nat.lib().ssrs_potential_workspace_bytes(rows, cols)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=cond.device)
+    stats = nat.SsrsSolveStats()
+    nat.check(nat.lib().ssrs_potential_solve(
+        nat.ptr(cond), nat.ptr(mask), nat.ptr(vals), nat.ptr(guess), nat.ptr(out),
+        rows, cols, C.c_double(rel_tol), int(max_iterations), nat.ptr(ws),
+        C.c_size_t(nbytes), C.byref(stats), stream_ptr()))
+    if not stats.converged:
+        import warnings
+        warnings.warn(f'potential solve stopped at |r|/|b| = {stats.residual:.3e} after '
+                      f'{stats.iterations} iterations (rel_tol {rel_tol:g})')
+    res = like_input(out, updraft)
+    if return_stats:
+        return res, dict(iterations=int(stats.iterations), converged=bool(stats.converged),
+                         residual=float(stats.residual), kernel_ms=float(stats.kernel_ms))
+    return res

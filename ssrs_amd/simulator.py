@@ -1,0 +1,428 @@
+"""`Simulator` -- the orchestrator of the hot path behind the reference's API
+(/root/reference/ssrs/simulator.py:34-386, 508-546, 760-763).
+
+Kept: constructor signature (`Simulator(in_config=None, **kwargs)`), the
+methods and attributes listed in SURVEY.md section 8(b), and the on-disk file
+contract (`<case>_orograph.npy` f32, `<id>_potential.npy` f32,
+`<id>_tracks.pkl` list of int16 (n,2), `summary_presence.npy` f32).
+
+Changed on purpose:
+  * the reference constructor downloads terrain/wind from the network
+    (simulator.py:88-125).  That L1 layer is out of scope; terrain and wind are
+    INJECTED: `Simulator(cfg, terrain=..., wind=...)`.
+  * the process pool over tracks (simulator.py:360-381) is one batched GPU call;
+    the random stream is Philox keyed by (sim_seed + real_id, track id, step).
+  * plotting methods are thin stubs (visualisation is out of scope).
+"""
+import json
+import os
+import pickle
+import time
+from dataclasses import asdict
+from datetime import datetime
+
+import numpy as np
+import torch
+
+from .config import Config
+from . import layers, movmodel, presence
+from . import potential as potential_mod
+from ._device import to_dev
+
+
+def _elapsed(start):
+    """'took' strings in the reference's format (utils.py:97-108)."""
+    hours, rem = divmod(time.time() - start, 3600)
+    mins, secs = divmod(rem, 60)
+    if hours == 0:
+        return f'{int(secs) + 1} sec' if mins == 0 else f'{int(mins)} min {int(secs)} sec'
+    return f'{int(hours)} hr {int(mins)} min'
+
+
+class Simulator(Config):
+    """ Class for SSRS simulation """
+
+    lonlat_crs = 'EPSG:4326'
+    time_format = 'y%Ym%md%dh%H'
+
+    def __init__(self, in_config: Config = None, *, terrain=None, wind=None,
+                 origin=(0.0, 0.0), **kwargs) -> None:
+        """terrain: 'synthetic' | elevation array (rows, cols) | dict with keys
+        'Elevation' and optionally 'Slope', 'Aspect' | callable(gridsize, res).
+        wind (snapshot / seasonal): list of dicts, each with 'datetime'
+        (datetime or 4-tuple) or 'case_id', and 'wspeed', 'wdirn' given either as
+        (rows, cols) rasters or as lattice samples with 'x_km', 'y_km'.
+        origin: projected (west, south) of cell (0, 0); the reference derives it
+        from southwest_lonlat through GDAL (simulator.py:77-85)."""
+        if in_config is None:
+            super().__init__(**kwargs)
+        else:
+            super().__init__(**asdict(in_config))
+        print(f'\n---- SSRS in {self.sim_mode} mode')
+        print(f'Run name: {self.run_name}')
+        if self.sim_seed >= 0:                                    # simulator.py:50-52
+            print('Specified random number seed:', self.sim_seed)
+            np.random.seed(self.sim_seed)
+
+        print(f'Output dir: {os.path.join(self.out_dir, self.run_name)}')
+        self.data_dir = os.path.join(self.out_dir, self.run_name, 'data/')
+        self.fig_dir = os.path.join(self.out_dir, self.run_name, 'figs/')
+        self.mode_data_dir = os.path.join(self.data_dir, self.sim_mode)
+        self.mode_fig_dir = os.path.join(self.fig_dir, self.sim_mode)
+        for dirname in (self.mode_data_dir, self.mode_fig_dir):
+            os.makedirs(dirname, exist_ok=True)
+        with open(os.path.join(self.out_dir, self.run_name, f'{self.run_name}.json'), 'w',
+                  encoding='utf-8') as cfile:
+            json.dump(self.__dict__, cfile, ensure_ascii=False, indent=2)
+
+        print(f'Terrain resolution = {self.resolution} m')
+        xsize = int(round((self.region_width_km[0] * 1000. / self.resolution)))
+        ysize = int(round((self.region_width_km[1] * 1000. / self.resolution)))
+        self.gridsize = (ysize, xsize)
+        print(f'Terrain grid size = {self.gridsize}')
+        west, south = float(origin[0]), float(origin[1])
+        self.bounds = (west, south, west + (xsize - 1) * self.resolution,
+                       south + (ysize - 1) * self.resolution)
+        self.extent = (self.bounds[0], self.bounds[2], self.bounds[1], self.bounds[3])
+        self.lonlat_bounds = None          # needs GDAL/PROJ; out of scope
+
+        self.terrain_layers = {'Elevation': 'DEM', 'Slope': 'Slope Degrees',
+                               'Aspect': 'Aspect Degrees'}
+        self._terrain = self._resolve_terrain(terrain)
+        self.turbines = None
+        self.wtk_layers = {
+            'wspeed': f'windspeed_{str(int(self.wtk_orographic_height))}m',
+            'wdirn': f'winddirection_{str(int(self.wtk_orographic_height))}m',
+            'pressure': f'pressure_{str(int(self.wtk_thermal_height))}m',
+            'temperature': f'temperature_{str(int(self.wtk_thermal_height))}m',
+            'blheight': 'boundary_layer_height',
+            'surfheatflux': 'surface_heat_flux',
+        }
+        self._presence_counts = {}        # (case_id, real_id) -> device histogram
+
+        if self.sim_mode.lower() != 'uniform':
+            if wind is None:
+                raise ValueError(f'{self.sim_mode} mode needs injected wind data (wind=[...]); '
+                                 'the WIND Toolkit download is out of scope')
+            self._wind = self._resolve_wind(wind)
+            self.dtimes = [w['datetime'] for w in self._wind]
+            self.case_ids = [w['case_id'] for w in self._wind]
+            self.compute_orographic_updrafts_using_wtk()
+        else:
+            print(f'Uniform mode: Wind speed = {self.uniform_windspeed} m/s')
+            print(f'Uniform mode: Wind dirn = {self.uniform_winddirn} deg(cw)')
+            self.case_ids = [self._get_uniform_id()]
+            self.compute_orographic_updraft_uniform()
+        for case_id in self.case_ids:
+            self.compute_thermal_updrafts(case_id)
+
+        fig_aspect = self.region_width_km[0] / self.region_width_km[1]
+        self.fig_size = (self.fig_height * fig_aspect, self.fig_height)
+        self.km_bar = min([1, 5, 10], key=lambda x: abs(x - self.region_width_km[0] // 4))
+        print('SSRS Simulator initiation done.')
+
+    # ------------------------------------------------------------ injection
+    def _resolve_terrain(self, terrain):
+        if terrain is None:
+            raise NotImplementedError(
+                'Terrain download (USGS 3DEP / SRTM, simulator.py:88-99) is outside the '
+                "hot-path scope: pass terrain='synthetic', an elevation array, a dict "
+                "{'Elevation': ..., 'Slope': ..., 'Aspect': ...} or a callable.")
+        if isinstance(terrain, str):
+            if terrain != 'synthetic':
+                raise ValueError(f'unknown terrain provider {terrain!r}')
+            from .synthetic import synthetic_dem
+            terrain = synthetic_dem(self.gridsize, self.resolution)
+        if callable(terrain):
+            terrain = terrain(self.gridsize, self.resolution)
+        if not isinstance(terrain, dict):
+            terrain = {'Elevation': terrain}
+        out = {}
+        for key, val in terrain.items():
+            arr = np.asarray(val.cpu() if isinstance(val, torch.Tensor) else val,
+                             dtype=np.float64)
+            if arr.shape != tuple(self.gridsize):
+                raise ValueError(f'terrain layer {key} has shape {arr.shape}, '
+                                 f'expected {tuple(self.gridsize)}')
+            out[key] = arr
+        if 'Elevation' not in out:
+            raise ValueError("terrain needs an 'Elevation' layer")
+        return out
+
+    def _resolve_wind(self, wind):
+        if isinstance(wind, dict):
+            wind = [dict(case_id=k, wspeed=v[0], wdirn=v[1]) for k, v in wind.items()]
+        out = []
+        for item in wind:
+            item = dict(item)
+            dt = item.get('datetime')
+            if dt is not None and not isinstance(dt, datetime):
+                dt = datetime(*dt)
+            if 'case_id' not in item:
+                if dt is None:
+                    raise ValueError("each wind entry needs 'datetime' or 'case_id'")
+                item['case_id'] = dt.strftime(self.time_format)       # simulator.py:126
+            item['datetime'] = dt
+            out.append(item)
+        if self.sim_mode.lower() == 'snapshot' and len(out) != 1:
+            raise ValueError('snapshot mode takes exactly one wind entry')
+        return out
+
+    # -------------------------------------------------------------- terrain
+    def get_terrain_elevation(self):
+        return self.get_terrain_layer('Elevation')
+
+    def get_terrain_slope(self):
+        """Injected 'Slope' layer, else the Horn-stencil fallback the reference
+        takes when the GeoTIFF is unavailable (simulator.py:152-159)."""
+        try:
+            return self.get_terrain_layer('Slope')
+        except KeyError:
+            return layers.compute_slope_degrees(self.get_terrain_elevation(), self.resolution)
+
+    def get_terrain_aspect(self):
+        try:
+            return self.get_terrain_layer('Aspect')
+        except KeyError:
+            return layers.compute_aspect_degrees(self.get_terrain_elevation(), self.resolution)
+
+    def get_terrain_layer(self, lname: str):
+        return self._terrain[lname]
+
+    def get_terrain_grid(self):
+        xgrid = np.linspace(self.bounds[0], self.bounds[0] + (self.gridsize[1] - 1) *
+                            self.resolution, self.gridsize[1])
+        ygrid = np.linspace(self.bounds[1], self.bounds[1] + (self.gridsize[0] - 1) *
+                            self.resolution, self.gridsize[0])
+        return xgrid, ygrid
+
+    # ------------------------------------------------------------- updrafts
+    def compute_orographic_updraft_uniform(self) -> None:
+        """simulator.py:189-198.  With only a DEM injected this is ONE fused
+        kernel (DEM -> orograph); with slope/aspect layers injected, the
+        elementwise kernel on those layers."""
+        print('Computing orographic updrafts..')
+        if 'Slope' in self._terrain or 'Aspect' in self._terrain:
+            orograph = layers.compute_orographic_updraft(
+                float(self.uniform_windspeed), float(self.uniform_winddirn),
+                self.get_terrain_slope(), self.get_terrain_aspect())
+        else:
+            orograph, _ = layers.updraft_from_dem(
+                self.get_terrain_elevation(), self.resolution,
+                float(self.uniform_windspeed), float(self.uniform_winddirn))
+        fname = self._get_orograph_fname(self.case_ids[0], self.mode_data_dir)
+        np.save(f'{fname}.npy', np.asarray(orograph, dtype=np.float32))
+
+    def compute_orographic_updrafts_using_wtk(self) -> None:
+        """simulator.py:200-215: one orograph per wind case, batched so the
+        terrain is read once for all cases."""
+        print('Computing orographic updrafts..', end="")
+        start_time = time.time()
+        slope = to_dev(self.get_terrain_slope(), torch.float64)
+        aspect = to_dev(self.get_terrain_aspect(), torch.float64)
+        batch = 8
+        for b0 in range(0, len(self._wind), batch):
+            chunk = self._wind[b0:b0 + batch]
+            ws, wd = [], []
+            for item in chunk:
+                s, d = self._wind_rasters(item)
+                ws.append(s)
+                wd.append(d)
+            oro, _ = layers.orographic_updraft(torch.stack(ws), torch.stack(wd), slope, aspect)
+            for item, o in zip(chunk, oro):
+                fname = self._get_orograph_fname(item['case_id'], self.mode_data_dir)
+                np.save(f'{fname}.npy', o.cpu().numpy())
+        print(f'took {_elapsed(start_time)}', flush=True)
+
+    def _wind_rasters(self, item):
+        """Per-cell wind speed / direction (f64 device tensors) of one case."""
+        ws, wd = item['wspeed'], item['wdirn']
+        if 'x_km' in item:
+            from .wind import interpolate_wind_lattice
+            return interpolate_wind_lattice(item['x_km'], item['y_km'], ws, wd,
+                                            self.gridsize, self.resolution)
+        ws = to_dev(ws, torch.float64)
+        wd = to_dev(wd, torch.float64)
+        if tuple(ws.shape) != tuple(self.gridsize) or tuple(wd.shape) != tuple(self.gridsize):
+            raise ValueError('wind rasters must have the terrain grid shape')
+        return ws, wd
+
+    def compute_thermal_updrafts(self, case_id: str):
+        """simulator.py:217-228."""
+        if self.thermals_realization_count > 0:
+            from .thermals import compute_thermals
+            print('Computing thermal updrafts...', flush=True)
+            aspect = self.get_terrain_aspect()
+            for real_id in range(self.thermals_realization_count):
+                seed = (self.sim_seed if self.sim_seed >= 0 else
+                        int.from_bytes(os.urandom(4), 'little')) + 7919 * (real_id + 1)
+                thermals = compute_thermals(aspect, 2.0, seed=seed)
+                fname = self._get_thermal_fname(case_id, real_id, self.mode_data_dir)
+                np.save(f'{fname}.npy', np.asarray(thermals, dtype=np.float32))
+        else:
+            print('No thermals requested!', flush=True)
+
+    def load_updrafts(self, case_id: str, apply_threshold=True):
+        """simulator.py:230-243 -> [orograph] + [orograph + thermal_k], each
+        passed through the threshold function (f64) when requested."""
+        fname = self._get_orograph_fname(case_id, self.mode_data_dir)
+        orograph = np.load(f'{fname}.npy')
+        updrafts = [orograph]
+        if self.thermals_realization_count > 0:
+            for real_id in range(self.thermals_realization_count):
+                fname = self._get_thermal_fname(case_id, real_id, self.mode_data_dir)
+                updrafts.append(orograph + np.load(f'{fname}.npy'))
+        if apply_threshold:
+            updrafts = [layers.get_above_threshold_speed(ix, self.updraft_threshold)
+                        for ix in updrafts]
+        return updrafts
+
+    def _get_orograph_fname(self, case_id: str, dirname: str = './'):
+        return os.path.join(dirname, f'{case_id}_orograph')
+
+    def _get_thermal_fname(self, case_id: str, real_id: int, dirname: str = './'):
+        return os.path.join(dirname, f'{case_id}_r{real_id}_thermals')
+
+    # ------------------------------------------------------------ potential
+    def get_directional_potential(self, updraft, case_id, real_id):
+        """simulator.py:259-288: cached `<id>_potential.npy` when its shape
+        matches, else the GPU solve; saved as f32."""
+        fname = self._get_potential_fname(case_id, real_id, self.mode_data_dir)
+        id_str = self._get_id_string(case_id, real_id)
+        try:
+            potential = np.load(f'{fname}.npy')
+            if potential.shape != self.gridsize:
+                raise FileNotFoundError
+            if (self.sim_seed < 0) & (real_id != 0):
+                raise FileNotFoundError
+            print(f'{id_str}: Found saved potential')
+        except FileNotFoundError as _:
+            start_time = time.time()
+            print(f'{id_str}: Computing potential..', end="", flush=True)
+            potential = potential_mod.solve_potential(np.asarray(updraft), self.track_direction)
+            print(f'took {_elapsed(start_time)}', flush=True)
+            np.save(f'{fname}.npy', potential.astype(np.float32))
+        if np.isnan(potential).any():
+            print('NANs found in potential!')
+        return potential
+
+    def _get_id_string(self, case_id: str, real_id=None):
+        """simulator.py:290-298: <case>_d<dir>_t<thr*100>_<model>[_r<k>]."""
+        out_str = (f'{case_id}_d{int(self.track_direction % 360)}'
+                   f'_t{int(self.updraft_threshold * 100)}_{self.movement_model}')
+        if real_id is not None:
+            out_str += f'_r{int(real_id)}'
+        return out_str
+
+    def _get_potential_fname(self, case_id: str, real_id: int, dirname: str):
+        return os.path.join(dirname, f'{self._get_id_string(case_id, real_id)}_potential')
+
+    def _get_tracks_fname(self, case_id: str, real_id: int, dirname: str):
+        return os.path.join(dirname, f'{self._get_id_string(case_id, real_id)}_tracks')
+
+    def _get_presence_fname(self, case_id: str, real_id: int, dirname: str):
+        return os.path.join(dirname, f'{self._get_id_string(case_id, real_id)}_presence')
+
+    def _get_uniform_id(self):
+        return f's{int(self.uniform_windspeed)}d{int(self.uniform_winddirn)}'
+
+    # --------------------------------------------------------------- tracks
+    def _stream_seed(self, real_id):
+        """Key of the Philox stream of one realisation: sim_seed + real_id, the
+        value the reference reseeds numpy with (simulator.py:351-352); a fresh
+        random key when the run is unseeded (sim_seed < 0)."""
+        if self.sim_seed >= 0:
+            return int(self.sim_seed) + int(real_id)
+        return int.from_bytes(os.urandom(7), 'little')
+
+    def simulate_tracks(self):
+        """simulator.py:332-386."""
+        print(f'Movement model = {self.movement_model}')
+        print(f'Updraft threshold = {self.updraft_threshold} m/s')
+        print(f'Movement direction = {self.track_direction} deg (cw)')
+        starting_rows, starting_cols = movmodel.get_starting_indices(
+            self.track_count, self.track_start_region, self.track_start_type,
+            self.region_width_km, self.resolution)
+        starts = np.stack([starting_rows, starting_cols], 1).astype(np.int32)
+        use_table = {'auto': None, 'table': True, 'direct': False}[self.stepper_path]
+        self.last_stats = {}
+        for case_id in self.case_ids:
+            updrafts = self.load_updrafts(case_id, apply_threshold=True)
+            for real_id, updraft in enumerate(updrafts):
+                if self.sim_seed > 0:
+                    np.random.seed(self.sim_seed + real_id)
+                id_str = self._get_id_string(case_id, real_id)
+                if self.movement_model == 'fluidflow':
+                    potential = self.get_directional_potential(updraft, case_id, real_id)
+                    fields = (updraft, potential)
+                elif self.movement_model == 'drw':
+                    fields = (None, None)
+                else:
+                    raise ValueError(f'unknown movement_model {self.movement_model!r}')
+                print(f'{id_str}: Simulating {self.track_count} tracks..', end="", flush=True)
+                start_time = time.time()
+                batch = movmodel.simulate_tracks(
+                    self.track_direction, starts, self.gridsize, self.track_dirn_restrict,
+                    self.track_stochastic_nu, fields[0], fields[1],
+                    seed=self._stream_seed(real_id), use_table=use_table,
+                    want_tracks=bool(self.save_tracks), steps_per_launch=self.steps_per_launch)
+                print(f'took {_elapsed(start_time)}', flush=True)
+                self._presence_counts[(case_id, real_id)] = batch.hist
+                self.last_stats[(case_id, real_id)] = batch.stats
+                if self.save_tracks:
+                    fname = self._get_tracks_fname(case_id, real_id, self.mode_data_dir)
+                    with open(f'{fname}.pkl', "wb") as fobj:
+                        pickle.dump(batch.tracks(), fobj)
+
+    # ------------------------------------------------------------- presence
+    def _counts_for(self, case_id, real_id):
+        hist = self._presence_counts.get((case_id, real_id))
+        if hist is not None:
+            return hist
+        fname = self._get_tracks_fname(case_id, real_id, self.mode_data_dir)
+        with open(f'{fname}.pkl', 'rb') as fobj:
+            tracks = pickle.load(fobj)
+        flat = np.concatenate(tracks) if len(tracks) else np.zeros((0, 2), dtype=np.int16)
+        return presence.compute_presence_counts(torch.from_numpy(flat).cuda(), self.gridsize)
+
+    def compute_presence_map(self, radius: float = 1000.):
+        """The numeric part of plot_presence_map (simulator.py:518-546): returns
+        the f32 summary map and writes summary_presence.npy."""
+        krad = presence.presence_kernel_radius(radius, self.resolution, self.gridsize)
+        dev = torch.device('cuda', torch.cuda.current_device())
+        summary = torch.zeros(self.gridsize, dtype=torch.float64, device=dev)
+        self.case_presence = {}
+        for case_id in self.case_ids:
+            nreal = 1 + int(self.thermals_realization_count)
+            case_prob = torch.zeros(self.gridsize, dtype=torch.float64, device=dev)
+            for real_id in range(nreal):
+                counts = self._counts_for(case_id, real_id)
+                prprob = presence.smooth_presence_counts(counts, krad)
+                presence.normalise_add(prprob, case_prob)       # prprob /= amax; case += prprob
+            presence.normalise_add(case_prob, summary)          # case /= amax; summary += case
+            self.case_presence[case_id] = case_prob
+        out = presence.normalise_to_f32(summary).cpu().numpy()  # summary /= amax -> f32
+        np.save(os.path.join(self.mode_data_dir, 'summary_presence.npy'), out)
+        return out
+
+    def plot_presence_map(self, plot_turbs=True, radius: float = 1000., show=False,
+                          minval=0.1, plot_all: bool = False) -> None:
+        """simulator.py:508-550 up to and including summary_presence.npy; the
+        matplotlib figures are out of scope."""
+        print('Plotting presence density map..')
+        self.compute_presence_map(radius)
+
+    # ------------------------------------------------ out-of-scope plotting
+    def _no_plot(self, name):
+        print(f'{name}: plotting is outside the hot-path scope of this build (no-op)')
+
+    def plot_terrain_features(self, *a, **k): self._no_plot('plot_terrain_features')
+    def plot_terrain_elevation(self, *a, **k): self._no_plot('plot_terrain_elevation')
+    def plot_terrain_slope(self, *a, **k): self._no_plot('plot_terrain_slope')
+    def plot_terrain_aspect(self, *a, **k): self._no_plot('plot_terrain_aspect')
+    def plot_wtk_layers(self, *a, **k): self._no_plot('plot_wtk_layers')
+    def plot_updrafts(self, *a, **k): self._no_plot('plot_updrafts')
+    def plot_directional_potentials(self, *a, **k): self._no_plot('plot_directional_potentials')
+    def plot_simulated_tracks(self, *a, **k): self._no_plot('plot_simulated_tracks')
+    def plot_windplant_presence_map(self, *a, **k): self._no_plot('plot_windplant_presence_map')
+    def plot_updraft_threshold_function(self, *a, **k): self._no_plot('plot_updraft_threshold_function')

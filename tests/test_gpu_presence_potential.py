@@ -1,0 +1,105 @@
+"""K3'/K4 presence density and K5 potential solver on the MI355X vs golden
+vectors from the reference (g5, g8, g9) and vs the oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def split(flat, lengths):
+    off = np.concatenate([[0], np.cumsum(lengths)])
+    return [flat[off[i]:off[i + 1]] for i in range(len(lengths))]
+
+
+def ulp_diff_f32(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float32).view(np.int32).astype(np.int64)
+    b = np.ascontiguousarray(b, dtype=np.float32).view(np.int32).astype(np.int64)
+    return np.abs(a - b)
+
+
+def test_presence_counts_and_smoothing_vs_golden(gpu, golden):
+    from ssrs_amd import movmodel, presence
+    g = golden('g9_presence.npz')
+    tracks = split(g['tracks'], g['lengths'])
+    counts = movmodel.compute_presence_counts(tracks, (40, 50))
+    assert np.array_equal(counts, g['counts'])                    # integers: exact
+    for rad in (2, 5, 13):
+        sm = movmodel.compute_smooth_presence_counts(tracks, (40, 50), rad)
+        assert sm.dtype == np.float32
+        # integer chord sums x 1/ntaps vs scipy's f64 accumulation: <= 1 f32 ulp
+        assert ulp_diff_f32(sm, g[f'smooth_r{rad}']).max() <= 1
+    with pytest.raises(ValueError):    # the reference raises IndexError here
+        movmodel.compute_presence_counts([np.array([[40, 0]], dtype=np.int16)], (40, 50))
+
+
+def test_presence_c1_golden(gpu, golden):
+    """C1: smoothed + normalised presence map of the 1000 reference tracks."""
+    from ssrs_amd import presence
+    g = golden('g8_c1.npz')
+    krad = int(g['krad'])
+    assert krad == presence.presence_kernel_radius(1000., 100., (500, 600))
+    sm = presence.smooth_presence_counts(torch.from_numpy(g['hist']).cuda(), krad)
+    assert abs(float(sm.max()) - float(g['presence_max_raw'])) <= 2e-7 * float(g['presence_max_raw'])
+    acc = torch.zeros((500, 600), dtype=torch.float64, device='cuda')
+    presence.normalise_add(sm, acc)                               # prprob /= amax; case += prprob
+    out = presence.normalise_to_f32(acc).cpu().numpy()
+    np.testing.assert_allclose(out[::8, ::8], g['presence_strided'], rtol=3e-7, atol=1e-9)
+    assert out.max() == 1.0
+
+
+def test_presence_smoothing_large_radius_vs_oracle(gpu):
+    from ssrs_amd import presence
+    from oracle import c_oracle
+    rng = np.random.default_rng(2)
+    cnt = rng.integers(0, 50, (70, 90)).astype(np.int32)
+    for rad in (2, 9, 35, 60):
+        got = presence.smooth_presence_counts(cnt, rad)
+        ref = c_oracle.smooth_presence(cnt.astype(np.uint32), rad)
+        assert ulp_diff_f32(got, ref).max() <= 1
+
+
+def test_boundary_nodes_vs_golden(golden):
+    from ssrs_amd.potential import get_boundary_nodes
+    g = golden('g5_potential.npz')
+    for dirn in (0., 180., -45., 90., 30.):
+        tag = f'd{int(dirn % 360)}'
+        bn, be = get_boundary_nodes(dirn, (48, 64))
+        assert np.array_equal(bn, g[f'bnodes_{tag}']) and np.array_equal(be, g[f'benergy_{tag}'])
+
+
+@pytest.mark.parametrize('dirn', [0., 180., 90., 30.])
+def test_potential_vs_reference_spsolve(gpu, golden, dirn):
+    """Matrix-free BiCGStab vs the reference's SuperLU solution (f32 output) on
+    the 48 x 64 golden.  The system is ill-conditioned (zero-updraft cells are
+    linked with 1e-8 conductances, movmodel.py:442-447), so a 1e-12 residual is
+    needed for a 0.1 (1e-4 of the 0..1000 range) agreement."""
+    from ssrs_amd.potential import solve_potential
+    g = golden('g5_potential.npz')
+    pot, st = solve_potential(g['updraft'], dirn, rel_tol=1e-12, max_iterations=100000,
+                              return_stats=True)
+    ref = g[f'pot_d{int(dirn % 360)}']
+    assert st['converged'], st
+    assert pot.dtype == np.float32 and pot.shape == ref.shape
+    np.testing.assert_allclose(pot, ref, rtol=0, atol=0.1)
+    # Dirichlet cells are reproduced exactly
+    from ssrs_amd.potential import dirichlet_rasters
+    mask, vals = dirichlet_rasters(dirn, ref.shape)
+    assert np.array_equal(pot[mask == 1], vals[mask == 1].astype(np.float32))
+
+
+@pytest.mark.xfail(reason='K5 v1 (unpreconditioned BiCGStab) stalls on high-contrast rasters: '
+                          'floating conductive clusters need a multilevel coarse space '
+                          '(DESIGN.md "K5", planned aggregation AMG)', strict=False)
+def test_potential_c1_vs_golden(gpu, golden):
+    from ssrs_amd import layers
+    from ssrs_amd.potential import solve_potential
+    g = golden('g8_c1.npz')
+    upd = layers.get_above_threshold_speed(g['orograph_f32'], 0.75)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        pot, st = solve_potential(upd, 0., rel_tol=1e-12, max_iterations=20000,
+                                  return_stats=True)
+    assert st['converged'], st
+    np.testing.assert_allclose(pot, g['potential'], rtol=0, atol=0.1)
