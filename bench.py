@@ -55,7 +55,7 @@ def cpu_baseline(args, gridsize, dem, pot, starts, seed, steps_per_track):
     a bounded sample of the same workload: the full-grid raster once and the
     first M tracks (same global ids / Philox streams as the GPU run)."""
     from oracle import c_oracle
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     t0 = time.perf_counter()
     slope, aspect = c_oracle.slope_aspect(dem, args.resolution)
     _, oro32 = c_oracle.orographic(slope, aspect, 10.0, 270.0)
