@@ -47,6 +47,8 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=20.0,
                     help='target CPU time of the cpu_baseline sample (0 = skip)')
     ap.add_argument('--potential', default='ramp', choices=['ramp', 'solve'])
+    ap.add_argument('--no-schedule', action='store_true', help='disable the coherent schedule')
+    ap.add_argument('--exact-only', action='store_true', help='disable the fast decision path')
     return ap.parse_args()
 
 
@@ -149,7 +151,8 @@ def main():
         out = movmodel.simulate_tracks(0.0, starts, gridsize, 1, 1.0, upd, pot, seed=seed,
                                        track_id_base=lo, table=table, use_table=not args.direct,
                                        hist=hist, steps_per_launch=args.steps_per_launch,
-                                       profile=True)
+                                       profile=True, exact_only=args.exact_only,
+                                       schedule=not args.no_schedule)
         reduce_histogram(hist, dst=0)
         ev[3].record()
         if timed:

@@ -111,7 +111,11 @@ typedef struct SsrsTrackParams {
     int32_t flags;            /* SSRS_TRACKS_* */
 } SsrsTrackParams;
 
-#define SSRS_TRACKS_PROFILE 1 /* time every launch with HIP events (stats) */
+#define SSRS_TRACKS_PROFILE 1    /* time every launch with HIP events (stats) */
+#define SSRS_TRACKS_NO_SCHEDULE 4 /* keep caller order, release every track at once
+                                    (A/B switch for the coherent schedule) */
+#define SSRS_TRACKS_EXACT_ONLY 2 /* disable the guarded division-free decision
+                                   (A/B switch; results are identical) */
 
 typedef struct SsrsTrackStats {
     int64_t total_steps; /* moves taken by all tracks of this call */

@@ -13,6 +13,8 @@ LIB_PATH = os.path.join(_HERE, 'libssrs_hip.so')
 SSRS_F32, SSRS_F64 = 0, 1
 SSRS_OK, SSRS_ERR_INVALID, SSRS_ERR_HIP, SSRS_ERR_START = 0, -1, -2, -3
 SSRS_TRACKS_PROFILE = 1
+SSRS_TRACKS_EXACT_ONLY = 2
+SSRS_TRACKS_NO_SCHEDULE = 4
 
 EXPORTS = (
     'ssrs_version', 'ssrs_last_error', 'ssrs_device_info', 'ssrs_slope_aspect',

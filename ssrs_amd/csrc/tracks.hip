@@ -24,6 +24,7 @@
 //     (pairwise-8 sums, sequential cumsum, f32 potential differences); built
 //     with -ffp-contract=off so no multiply-add is fused.
 #include <rocrand/rocrand_philox4x32_10.h>
+#include <hipcub/hipcub.hpp>
 
 #include <cmath>
 #include <cstring>
@@ -109,8 +110,18 @@ __device__ __forceinline__ double sum9(const double *x)
 
 // generate_move_probabilities (movmodel.py:220-244) followed by
 // np.random.choice's inverse-cdf pick.  w[9] raw weights (w[4] ignored unless NaN).
+//
+// The reference normalises twice and divides the running sums by their last
+// element before comparing with u: 26 f64 divisions per step that only matter
+// when u lands within rounding distance of a cdf boundary.  `fast` evaluates the
+// same comparison on the UNNORMALISED running sums C_k against u * C_8 and
+// falls back to the exact sequence whenever any |C_k - u C_8| is within
+// 2^-46 relative: the exact path's cdf_k equals C_k / C_8 up to < 2^-48 (all
+// terms non-negative, <= 22 roundings of 2^-53 each), and C_k, u C_8 carry
+// <= 9 roundings, so outside that band both paths take the same decision.  The
+// result is therefore always the reference's, bit for bit.
 __device__ __forceinline__ int choose_move(const double *w, const double *prior, double nu,
-                                           uint32_t mask, double u)
+                                           uint32_t mask, double u, bool fast)
 {
     double q[9];
     bool has_nan = false;
@@ -125,19 +136,37 @@ __device__ __forceinline__ int choose_move(const double *w, const double *prior,
     bool any = false;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
-        q[k] = q[k] * static_cast<double>((mask >> k) & 1u);
+        const double z = q[k] * 0.0;                               // ix * float(iy)
+        q[k] = ((mask >> k) & 1u) ? q[k] : z;
         any |= (q[k] != 0.0);
     }
     if (!any) {                                   // all masked weights are zero
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            q[k] = (k == 4 ? 0.0 : prior[k]) * static_cast<double>((mask >> k) & 1u);
+            q[k] = ((mask >> k) & 1u) && k != 4 ? prior[k] : 0.0;
             any |= (q[k] != 0.0);
         }
         if (!any) {                               // prior fully masked as well
 #pragma unroll
             for (int k = 0; k < 9; ++k) q[k] = prior[k];
         }
+    }
+    if (fast) {
+        double c[8];
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { acc = acc + q[k]; c[k] = acc; }
+        const double ut = u * (acc + q[8]);
+        const double band = ut * 0x1p-46;
+        int idx = 0;
+        bool near = false;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const double d = c[k] - ut;
+            idx += d <= 0.0 ? 1 : 0;
+            near |= !(fabs(d) > band);            // also true for NaN / inf
+        }
+        if (!near) return idx;
     }
     const double s1 = sum9(q);
 #pragma unroll
@@ -159,6 +188,35 @@ __device__ __forceinline__ int choose_move(const double *w, const double *prior,
 #pragma unroll
     for (int k = 0; k < 9; ++k) idx += (cdf[k] / cdf[8] <= u) ? 1 : 0;
     return idx;
+}
+
+// Table-mode decision on the 8 pre-clipped weights of one cell (entry j is
+// neighbour k = j < 4 ? j : j + 1).  Same guarded comparison as choose_move's
+// fast branch, minus everything the table builder already did (clip, NaN
+// poisoning).  Returns -1 when the exact sequence must decide: a cdf boundary
+// within 2^-46 of u, an all-zero / NaN (poisoned) / infinite masked row.
+__device__ __forceinline__ int choose_table_fast(const double *t, uint32_t mask, double u)
+{
+    double c[8];
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = j < 4 ? j : j + 1;
+        acc = acc + (((mask >> k) & 1u) ? t[j] : 0.0);
+        c[j] = acc;
+    }
+    const double ut = u * acc;
+    const double band = ut * 0x1p-46;
+    int idx = 0;
+    bool near = !(acc > 0.0);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {               // k = 8 is never counted: cdf_8 = 1 > u
+        const double d = c[j] - ut;
+        const int le = d <= 0.0 ? 1 : 0;
+        idx += (j == 3) ? 2 * le : le;          // cdf_4 == cdf_3 (centre weight is 0)
+        near |= !(fabs(d) > band);
+    }
+    return near ? -1 : idx;
 }
 
 // Raw 3x3 move weights of movmodel.py:292-306 at an interior cell.
@@ -228,15 +286,59 @@ struct alignas(16) TrackState {
     int32_t pos;     // row | col << 16   (both < 32768)
     int32_t k;       // moves taken; < 0 = dead (bad start cell)
     uint32_t dirs;   // last 8 move indices, 4 bits each, newest in bits 0-3
-    uint32_t run;    // AND of restrictions over the whole history (memory == 0)
+    uint32_t aux;    // bits 0-8: AND of restrictions over the whole history
+                     // (memory == 0); bits 9-31: release step (coherent schedule)
 };
 
 struct alignas(16) TrackCtl {
     uint32_t count[4];           // live tracks entering launch i at count[i & 3]
     uint32_t error;              // != 0: some start cell was outside the raster
-    uint32_t pad;
+    uint32_t par_min;            // smallest along-track start coordinate (schedule)
     unsigned long long steps;    // total moves taken
 };
+
+// Coherent schedule.  Tracks are independent, so the order in which lanes pick
+// them up and the global step at which each one starts are free choices that
+// cannot change any result (the uniform is keyed by track id and the track's
+// own step count).  Both are chosen for locality: tracks are sorted by their
+// across-track coordinate (lanes of a wave walk neighbouring columns) and a
+// track that starts d cells ahead of the rearmost one along the movement
+// direction is released d steps later, so the whole batch sweeps the raster as
+// one front a few rows deep: table rows and histogram rows are then shared
+// through L2 instead of being re-fetched from HBM by every track.
+struct PlanGeom {
+    double cos_t, sin_t;   // movement direction (north = +row, clockwise)
+    int offset;            // rows + cols: makes both coordinates non-negative
+};
+__device__ __forceinline__ void plan_coords(const PlanGeom &g, int row, int col, int &par, int &perp)
+{
+    par = static_cast<int>(lrint(row * g.cos_t + col * g.sin_t)) + g.offset;
+    perp = static_cast<int>(lrint(col * g.cos_t - row * g.sin_t)) + g.offset;
+}
+
+__global__ __launch_bounds__(kBlock) void k_plan_keys(const int32_t *__restrict__ start_rc,
+                                                     long long ntracks, PlanGeom g,
+                                                     unsigned long long *__restrict__ keys,
+                                                     int32_t *__restrict__ vals, TrackCtl *ctl)
+{
+    const long long t = blockIdx.x * static_cast<long long>(kBlock) + threadIdx.x;
+    int par = 0x7fffffff;
+    if (t < ntracks) {
+        int perp;
+        plan_coords(g, start_rc[2 * t], start_rc[2 * t + 1], par, perp);
+        par = par < 0 ? 0 : par;
+        perp = perp < 0 ? 0 : perp;
+        keys[t] = (static_cast<unsigned long long>(perp) << 20) | static_cast<unsigned>(par & 0xFFFFF);
+        vals[t] = static_cast<int32_t>(t);
+    }
+    // wave minimum, one atomic per wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int o = __shfl_down(par, off);
+        par = o < par ? o : par;
+    }
+    if ((threadIdx.x & 63) == 0 && par != 0x7fffffff) atomicMin(&ctl->par_min, static_cast<uint32_t>(par));
+}
 
 enum { MODE_PRIOR = 0, MODE_UPDRAFT = 1, MODE_FLUIDFLOW = 2, MODE_TABLE = 3 };
 
@@ -259,26 +361,36 @@ struct StepArgs {
     int32_t *list_out;
     TrackCtl *ctl;
     int launch;                  // index of this launch
+    int fast;                    // guarded division-free decision (see choose_move)
     int steps;                   // S
+    int coherent;                // tracks carry a release step in aux
 };
 
 __global__ __launch_bounds__(kBlock) void k_tracks_init(
     const int32_t *__restrict__ start_rc, long long ntracks, int rows, int cols,
     uint32_t *hist, int16_t *traj, const long long *traj_off, int32_t *lengths,
-    int16_t *end_rc, TrackState *state, TrackCtl *ctl)
+    int16_t *end_rc, TrackState *state, TrackCtl *ctl, PlanGeom g, int coherent)
 {
     const long long t = blockIdx.x * static_cast<long long>(kBlock) + threadIdx.x;
     if (t == 0) {
         ctl->count[0] = static_cast<uint32_t>(ntracks);
         ctl->count[1] = ctl->count[2] = ctl->count[3] = 0;
-        ctl->pad = 0;
         ctl->steps = 0;
     }
     if (t >= ntracks) return;
     const int row = start_rc[2 * t], col = start_rc[2 * t + 1];
     TrackState s;
     s.dirs = 0x44444444u;        // "no move yet" = (0,0) in every history slot
-    s.run = kAllButCentre;
+    uint32_t delay = 0;
+    if (coherent) {
+        int par, perp;
+        plan_coords(g, row, col, par, perp);
+        par = par < 0 ? 0 : par;
+        const uint32_t pmin = ctl->par_min;
+        delay = static_cast<uint32_t>(par) > pmin ? static_cast<uint32_t>(par) - pmin : 0u;
+        if (delay > 0x7FFFFFu) delay = 0x7FFFFFu;
+    }
+    s.aux = kAllButCentre | (delay << 9);
     if (row < 0 || col < 0 || row >= rows || col >= cols) {
         atomicOr(&ctl->error, 1u);
         s.pos = 0;
@@ -314,26 +426,51 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
     active = active && s.k >= 0;
     int row = s.pos & 0xFFFF, col = (s.pos >> 16) & 0xFFFF;
     long long k = s.k;
-    uint32_t dirs = s.dirs, run = s.run;
+    uint32_t dirs = s.dirs, run = s.aux & 0x1FFu;
+    const long long release = a.coherent ? static_cast<long long>(s.aux >> 9) : 0;
+    const long long g0 = static_cast<long long>(a.launch) * a.steps;   // global step of it = 0
     const unsigned long long track = a.track_base + static_cast<unsigned long long>(t);
     const long long toff = (a.traj && active) ? a.traj_off[t] : 0;
     uint32_t pend_a = 0, pend_b = 0;   // words (2,3) of the current Philox block
     bool have_pending = false;
     uint32_t moved = 0;
 
+    const int lane_id = threadIdx.x & 63;
+
+    // Loop head of movmodel.py:285-291 for the track's current (row, col, k):
+    // `done` = the while/break exit, (er, ec) = the cell whose 3x3 window the
+    // step evaluates (the burn-in nudge applied).  Evaluated one step ahead so
+    // that the table entry of (er, ec) can be fetched before it is needed.
+    bool done = false;
+    int er = row, ec = col;
+    auto loop_head = [&]() {
+        done = !(k < a.max_k);
+        er = row;
+        ec = col;
+        if (!done) {
+            if (k > a.burnin) {
+                done = !(0 < row && row < a.rows - 1 && 0 < col && col < a.cols - 1);
+            } else {
+                if (er <= 1) er += 2; else if (er >= a.rows - 2) er -= 2;
+                if (ec <= 0) ec += 2; else if (ec >= a.cols - 2) ec -= 2;
+            }
+        }
+    };
+    double2 t0 = {0.0, 0.0}, t1 = t0, t2 = t0, t3 = t0;      // prefetched table entry
+    auto fetch_entry = [&]() {
+        if (MODE == MODE_TABLE) {
+            const double2 *src = reinterpret_cast<const double2 *>(
+                a.table + (static_cast<size_t>(er) * a.cols + ec) * 8);
+            t0 = src[0]; t1 = src[1]; t2 = src[2]; t3 = src[3];
+        }
+    };
+    if (active) loop_head();
+    fetch_entry();
+
     for (int it = 0; it < a.steps; ++it) {
         if (!__any(active)) break;
-        if (active) {
-            // loop head of movmodel.py:285-291
-            bool done = !(k < a.max_k);
-            if (!done) {
-                if (k > a.burnin) {
-                    done = !(0 < row && row < a.rows - 1 && 0 < col && col < a.cols - 1);
-                } else {
-                    if (row <= 1) row += 2; else if (row >= a.rows - 2) row -= 2;
-                    if (col <= 0) col += 2; else if (col >= a.cols - 2) col -= 2;
-                }
-            }
+        bool stepped = false;
+        if (active && g0 + it >= release) {
             if (done) {
                 if (a.lengths) a.lengths[t] = static_cast<int32_t>(k + 1);
                 if (a.end_rc)
@@ -352,22 +489,6 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
                 }
                 have_pending = !(k & 1);
                 const double u = words_to_uniform(wa, wb);
-                // ---- raw weights
-                double w[9];
-                if (MODE == MODE_TABLE) {
-                    const double2 *src = reinterpret_cast<const double2 *>(
-                        a.table + (static_cast<size_t>(row) * a.cols + col) * 8);
-                    const double2 t0 = src[0], t1 = src[1], t2 = src[2], t3 = src[3];
-                    w[0] = t0.x; w[1] = t0.y; w[2] = t1.x; w[3] = t1.y; w[4] = 0.0;
-                    w[5] = t2.x; w[6] = t2.y; w[7] = t3.x; w[8] = t3.y;
-                } else if (MODE == MODE_FLUIDFLOW) {
-                    window_weights<true>(a.updraft, a.potential, a.cols, row, col, w);
-                } else if (MODE == MODE_UPDRAFT) {
-                    window_weights<false>(a.updraft, a.potential, a.cols, row, col, w);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 9; ++j) w[j] = a.prior[j];
-                }
                 // ---- direction memory (movmodel.py:307-309)
                 uint32_t mask = kAllButCentre;
                 if (a.memory == 0) {
@@ -379,24 +500,58 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
                         d >>= 4;
                     }
                 }
-                const int idx = choose_move(w, a.prior, a.nu, mask, u);
-                row += idx / 3 - 1;
-                col += idx % 3 - 1;
+                // ---- weights + decision
+                int idx = -1;
+                if (MODE == MODE_TABLE) {
+                    const double tt[8] = {t0.x, t0.y, t1.x, t1.y, t2.x, t2.y, t3.x, t3.y};
+                    if (a.fast) idx = choose_table_fast(tt, mask, u);
+                    if (idx < 0) {
+                        const double w[9] = {tt[0], tt[1], tt[2], tt[3], 0.0, tt[4], tt[5], tt[6], tt[7]};
+                        idx = choose_move(w, a.prior, a.nu, mask, u, false);
+                    }
+                } else {
+                    double w[9];
+                    if (MODE == MODE_FLUIDFLOW) {
+                        window_weights<true>(a.updraft, a.potential, a.cols, er, ec, w);
+                    } else if (MODE == MODE_UPDRAFT) {
+                        window_weights<false>(a.updraft, a.potential, a.cols, er, ec, w);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 9; ++j) w[j] = a.prior[j];
+                    }
+                    idx = choose_move(w, a.prior, a.nu, mask, u, a.fast != 0);
+                }
+                row = er + idx / 3 - 1;
+                col = ec + idx % 3 - 1;
                 dirs = (dirs << 4) | static_cast<uint32_t>(idx);
                 run &= restriction_of(static_cast<uint32_t>(idx));
                 ++k;
                 ++moved;
-                if (a.hist) atomicAdd(&a.hist[static_cast<size_t>(row) * a.cols + col], 1u);
+                stepped = true;
+                loop_head();                       // head of the NEXT step
                 if (a.traj)
                     reinterpret_cast<uint32_t *>(a.traj)[toff + k] =
                         static_cast<uint32_t>(row & 0xFFFF) | (static_cast<uint32_t>(col) << 16);
             }
         }
+        // Next step's table entry: fetched by EVERY lane at the top level of the
+        // loop (no divergent phi, so the compiler does not wait on it here) and
+        // BEFORE this step's histogram atomic: vmcnt retires in issue order, so
+        // a fetch queued behind the atomic would pay the atomic's latency too.
+        // (er, ec) is always a cell of the raster, also for finished lanes.
+        fetch_entry();
+        // ---- presence histogram (K3).  Issued by every lane on every iteration
+        // (idle lanes add 0 to their own, valid, cell): with exactly one VMEM
+        // op behind the four fetches the compiler can wait for the fetches with
+        // vmcnt(1) and leave the atomic in flight; a conditional atomic forces
+        // vmcnt(0) and puts the atomic's round trip on every step's critical path.
+        if (a.hist)
+            atomicAdd(&a.hist[static_cast<size_t>(row) * a.cols + col], stepped ? 1u : 0u);
     }
 
     // ---- wave-level compaction of the survivors into the next launch's list
     const unsigned long long live = __ballot(active);
-    const int lane = threadIdx.x & 63;
+    const int lane = lane_id;
     const int nsurv = __popcll(live);
     uint32_t base = 0;
     if (lane == 0 && nsurv) base = atomicAdd(&ctl->count[out_slot], static_cast<uint32_t>(nsurv));
@@ -408,7 +563,7 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
         o.pos = row | (col << 16);
         o.k = static_cast<int32_t>(k);
         o.dirs = dirs;
-        o.run = run;
+        o.aux = run | (s.aux & ~0x1FFu);
         a.state[t] = o;
     }
     // one atomic per wave for the step total
@@ -424,7 +579,20 @@ struct Workspace {
     TrackCtl *ctl;
     TrackState *state;
     int32_t *list[2];
+    unsigned long long *keys[2];
+    void *sort_temp;
+    size_t sort_temp_bytes;
 };
+
+static size_t sort_temp_size(int64_t n)
+{
+    size_t bytes = 0;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, static_cast<const unsigned long long *>(nullptr),
+                                       static_cast<unsigned long long *>(nullptr),
+                                       static_cast<const int32_t *>(nullptr),
+                                       static_cast<int32_t *>(nullptr), static_cast<int>(n), 0, 40);
+    return bytes;
+}
 
 static size_t workspace_layout(int64_t n, char *base, Workspace *ws)
 {
@@ -437,6 +605,13 @@ static size_t workspace_layout(int64_t n, char *base, Workspace *ws)
         if (ws) ws->list[i] = reinterpret_cast<int32_t *>(base + off);
         off = align_up(off + sizeof(int32_t) * static_cast<size_t>(n), 256);
     }
+    for (int i = 0; i < 2; ++i) {
+        if (ws) ws->keys[i] = reinterpret_cast<unsigned long long *>(base + off);
+        off = align_up(off + sizeof(unsigned long long) * static_cast<size_t>(n), 256);
+    }
+    const size_t temp = n > 0 ? sort_temp_size(n) : 0;
+    if (ws) { ws->sort_temp = base + off; ws->sort_temp_bytes = temp; }
+    off = align_up(off + temp, 256);
     return off;
 }
 
@@ -552,12 +727,32 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
     SSRS_HIP_CHECK(hipEventCreate(&ev_first));
     SSRS_HIP_CHECK(hipEventCreate(&ev_last));
     SSRS_HIP_CHECK(hipEventRecord(ev_first, st));
+    const bool coherent = (p->flags & SSRS_TRACKS_NO_SCHEDULE) == 0;
+    PlanGeom geom = {};
     {
         const unsigned blocks = static_cast<unsigned>((ntracks + kBlock - 1) / kBlock);
+        if (coherent) {
+            // movement direction from the prior: its lobe peaks along the heading
+            // (movmodel.py:247-257), so the weighted neighbour offsets give it back
+            double vr = 0.0, vc = 0.0;
+            for (int k = 0; k < 9; ++k) { vr += p->prior[k] * dr_of(k); vc += p->prior[k] * dc_of(k); }
+            const double nrm = std::sqrt(vr * vr + vc * vc);
+            geom.cos_t = nrm > 0.0 ? vr / nrm : 1.0;
+            geom.sin_t = nrm > 0.0 ? vc / nrm : 0.0;
+            geom.offset = p->rows + p->cols;
+            SSRS_HIP_CHECK(hipMemsetAsync(&ws.ctl->par_min, 0xFF, sizeof(uint32_t), st));
+            hipLaunchKernelGGL(k_plan_keys, dim3(blocks), dim3(kBlock), 0, st, start_rc,
+                               static_cast<long long>(ntracks), geom, ws.keys[0], ws.list[1], ws.ctl);
+            SSRS_HIP_CHECK(hipGetLastError());
+            size_t temp_bytes = ws.sort_temp_bytes;
+            SSRS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(
+                ws.sort_temp, temp_bytes, ws.keys[0], ws.keys[1], ws.list[1], ws.list[0],
+                static_cast<int>(ntracks), 0, 40, st));
+        }
         hipLaunchKernelGGL(k_tracks_init, dim3(blocks), dim3(kBlock), 0, st, start_rc,
                            static_cast<long long>(ntracks), p->rows, p->cols, hist, traj,
                            reinterpret_cast<const long long *>(traj_offsets), lengths, end_rc,
-                           ws.state, ws.ctl);
+                           ws.state, ws.ctl, geom, coherent ? 1 : 0);
         SSRS_HIP_CHECK(hipGetLastError());
     }
 
@@ -570,6 +765,8 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
     a.hist = hist; a.end_rc = end_rc; a.lengths = lengths; a.traj = traj;
     a.traj_off = reinterpret_cast<const long long *>(traj_offsets);
     a.state = ws.state; a.ctl = ws.ctl; a.steps = S;
+    a.fast = ((p->flags & SSRS_TRACKS_EXACT_ONLY) == 0 && p->scaling_parameter == 1.0) ? 1 : 0;
+    a.coherent = coherent ? 1 : 0;
 
     // Launch loop.  Launches are queued kBatch deep; the live count of a batch
     // is copied back asynchronously and examined while the next batch runs, so
@@ -588,7 +785,7 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
     while (!finished && rc == SSRS_OK) {
         for (int j = 0; j < kBatch; ++j, ++launch) {
             a.launch = launch;
-            a.list_in = launch == 0 ? nullptr : ws.list[launch & 1];
+            a.list_in = (launch == 0 && !coherent) ? nullptr : ws.list[launch & 1];
             a.list_out = ws.list[(launch + 1) & 1];
             const unsigned blocks = (upper + kBlock - 1) / kBlock;
             if (profile) {

@@ -75,7 +75,7 @@ def get_directional_probs(theta):
 
 
 def make_track_params(grid_shape, move_dirn, memory_parameter=1, scaling_parameter=1.,
-                      steps_per_launch=0, profile=False):
+                      steps_per_launch=0, profile=False, exact_only=False, schedule=True):
     rows, cols = int(grid_shape[0]), int(grid_shape[1])
     p = nat.SsrsTrackParams()
     nat.check(nat.lib().ssrs_track_params_init(C.byref(p), rows, cols, int(memory_parameter),
@@ -84,7 +84,9 @@ def make_track_params(grid_shape, move_dirn, memory_parameter=1, scaling_paramet
     for k in range(9):
         p.prior[k] = float(prior[k])
     p.steps_per_launch = int(steps_per_launch)
-    p.flags = nat.SSRS_TRACKS_PROFILE if profile else 0
+    p.flags = (nat.SSRS_TRACKS_PROFILE if profile else 0) | \
+        (nat.SSRS_TRACKS_EXACT_ONLY if exact_only else 0) | \
+        (0 if schedule else nat.SSRS_TRACKS_NO_SCHEDULE)
     return p
 
 
@@ -124,7 +126,8 @@ class TrackBatch:
 def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
                     scaling_parameter=1., updraft_field=None, potential_field=None, *,
                     seed=0, track_id_base=0, table=None, use_table=None, hist=None,
-                    want_hist=True, want_tracks=False, steps_per_launch=0, profile=False):
+                    want_hist=True, want_tracks=False, steps_per_launch=0, profile=False,
+                    exact_only=False, schedule=True):
     """generate_simulated_tracks for a whole batch (movmodel.py:264-318 under
     simulator.py:360-369) + presence histogram (movmodel.py:410-419).
 
@@ -154,7 +157,7 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
         if use_table:
             table = build_transition_table(upd, pot)
     p = make_track_params((rows, cols), move_dirn, memory_parameter, scaling_parameter,
-                          steps_per_launch, profile)
+                          steps_per_launch, profile, exact_only, schedule)
     if hist is None and want_hist:
         hist = torch.zeros((rows, cols), dtype=torch.int32, device=dev)
     lengths = torch.empty(n, dtype=torch.int32, device=dev)
