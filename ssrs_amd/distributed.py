@@ -45,8 +45,9 @@ def gather_track_summaries(lengths, ends, dst=0, group=None):
     dist.all_gather(sizes, torch.tensor([lengths.numel()], dtype=torch.int64,
                                         device=lengths.device), group=group)
     nmax = int(max(int(s.item()) for s in sizes))
-    pad_l = torch.zeros(nmax, dtype=lengths.dtype, device=lengths.device)
-    pad_e = torch.zeros((nmax, 2), dtype=ends.dtype, device=ends.device)
+    # int32 on the wire: gloo has no int16 collectives
+    pad_l = torch.zeros(nmax, dtype=torch.int32, device=lengths.device)
+    pad_e = torch.zeros((nmax, 2), dtype=torch.int32, device=ends.device)
     pad_l[:lengths.numel()] = lengths
     pad_e[:ends.shape[0]] = ends
     outs_l = [torch.zeros_like(pad_l) for _ in range(world)] if rank == dst else None
@@ -55,5 +56,5 @@ def gather_track_summaries(lengths, ends, dst=0, group=None):
     dist.gather(pad_e, outs_e, dst=dst, group=group)
     if rank != dst:
         return None, None
-    return ([o[:int(s.item())] for o, s in zip(outs_l, sizes)],
-            [o[:int(s.item())] for o, s in zip(outs_e, sizes)])
+    return ([o[:int(s.item())].to(lengths.dtype) for o, s in zip(outs_l, sizes)],
+            [o[:int(s.item())].to(ends.dtype) for o, s in zip(outs_e, sizes)])

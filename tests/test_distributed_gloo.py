@@ -1,0 +1,82 @@
+"""N > 1 path on CPU: two gloo ranks shard the track ids, each produces its
+shard's histogram (here with the C oracle standing in for the GPU stepper --
+the sharding + reduce host logic is what is under test), and the reduced
+histogram must equal the single-process run bit for bit."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _case():
+    from oracle import ssrs_oracle as orc
+    from ssrs_amd.synthetic import synthetic_dem
+    rows, cols = 64, 80
+    z = synthetic_dem((rows, cols), 100.)
+    oro = orc.compute_orographic_updraft(10., 270., orc.compute_slope_degrees(z, 100.),
+                                         orc.compute_aspect_degrees(z, 100.)).astype(np.float32)
+    upd = orc.get_above_threshold_speed(oro, 0.75)
+    pot = (1000. * (1 - np.arange(rows)[:, None] / (rows - 1.)) * np.ones((1, cols))).astype(np.float32)
+    rng = np.random.default_rng(0)
+    starts = np.stack([rng.integers(1, 8, 301), rng.integers(0, cols, 301)], 1)
+    return (rows, cols), upd, pot, starts
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from oracle import c_oracle
+    from ssrs_amd.distributed import shard_range, reduce_histogram, gather_track_summaries
+    shape, upd, pot, starts = _case()
+    lo, hi = shard_range(len(starts), rank, world)
+    res = c_oracle.simulate_tracks(0., starts[lo:hi], shape, 1, 1., upd, pot, seed=30,
+                                   track_id_base=lo, want_traj=False, nthreads=1)
+    hist = torch.from_numpy(res['hist'].view(np.int32).copy())
+    reduce_histogram(hist, dst=0)
+    lens, ends = gather_track_summaries(torch.from_numpy(res['lengths']),
+                                        torch.from_numpy(res['ends']), dst=0)
+    if rank == 0:
+        np.save(os.path.join(out_dir, 'hist.npy'), hist.numpy())
+        np.save(os.path.join(out_dir, 'lengths.npy'), torch.cat(lens).numpy())
+        np.save(os.path.join(out_dir, 'ends.npy'), torch.cat(ends).numpy())
+    # all_ranks=True leaves the same sum everywhere
+    h2 = torch.from_numpy(res['hist'].view(np.int32).copy())
+    reduce_histogram(h2, all_ranks=True)
+    np.save(os.path.join(out_dir, f'all_{rank}.npy'), h2.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_histogram_reduce_equals_single_run(tmp_path, world):
+    from oracle import c_oracle
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    shape, upd, pot, starts = _case()
+    ref = c_oracle.simulate_tracks(0., starts, shape, 1, 1., upd, pot, seed=30, want_traj=False,
+                                   nthreads=2)
+    hist = np.load(tmp_path / 'hist.npy').view(np.uint32)
+    assert np.array_equal(hist, ref['hist'])
+    assert np.array_equal(np.load(tmp_path / 'lengths.npy'), ref['lengths'])
+    assert np.array_equal(np.load(tmp_path / 'ends.npy'), ref['ends'])
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f'all_{r}.npy').view(np.uint32), ref['hist'])
+
+
+def test_reduce_is_noop_without_process_group():
+    from ssrs_amd.distributed import reduce_histogram
+    h = torch.arange(12, dtype=torch.int32).reshape(3, 4)
+    assert reduce_histogram(h) is h

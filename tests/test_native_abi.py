@@ -1,0 +1,66 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol that
+include/ssrs_hip.h declares; argument validation runs before any GPU work."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, 'include', 'ssrs_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(ssrs_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_symbols_are_exported():
+    from ssrs_amd import _native
+    lib = _native.lib()
+    names = declared_functions()
+    assert len(names) >= 18
+    for name in names:
+        assert hasattr(lib, name), f'{name} declared in ssrs_hip.h but not exported'
+    assert sorted(_native.EXPORTS) == names, 'ssrs_amd._native.EXPORTS out of sync with the header'
+
+
+def test_version_and_error_text():
+    from ssrs_amd import _native
+    lib = _native.lib()
+    assert lib.ssrs_version() == 100
+    assert isinstance(lib.ssrs_last_error(), bytes)
+
+
+def test_argument_validation_needs_no_gpu():
+    from ssrs_amd import _native
+    lib = _native.lib()
+    rc = lib.ssrs_slope_aspect(None, 1, C.c_double(10.), None, None, 1, 10, 10, None)
+    assert rc == _native.SSRS_ERR_INVALID and b'dem is NULL' in lib.ssrs_last_error()
+    rc = lib.ssrs_threshold_updraft(None, C.c_double(0.75), None, C.c_size_t(4), None)
+    assert rc == _native.SSRS_ERR_INVALID
+    p = _native.SsrsTrackParams()
+    assert lib.ssrs_track_params_init(C.byref(p), 500, 600, 1, C.c_double(1.0)) == 0
+    assert (p.rows, p.cols, p.burnin, p.max_moves) == (500, 600, 50, 75000)
+    assert lib.ssrs_track_params_init(C.byref(p), 5000, 6000, 1, C.c_double(1.0)) == 0
+    assert (p.burnin, p.max_moves) == (500, 7500000)
+    assert lib.ssrs_track_params_init(C.byref(p), 31, 33, 3, C.c_double(1.0)) == 0
+    assert (p.burnin, p.max_moves, p.memory_parameter) == (3, 256, 3)    # ceil(255.75)
+    assert lib.ssrs_track_params_init(C.byref(p), 3, 600, 1, C.c_double(1.0)) == _native.SSRS_ERR_INVALID
+    p.memory_parameter = 9
+    rc = lib.ssrs_tracks_simulate(C.byref(p), None, None, None, None, C.c_int64(1), C.c_uint64(0),
+                                  C.c_uint64(0), None, None, None, None, None, None,
+                                  C.c_size_t(0), None, None)
+    assert rc == _native.SSRS_ERR_INVALID
+    with pytest.raises(ValueError):
+        _native.check(rc)
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    import numpy as np
+    from ssrs_amd import layers
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        layers.compute_slope_degrees(np.zeros((8, 8)), 10.)
