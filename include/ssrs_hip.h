@@ -95,6 +95,31 @@ int ssrs_updraft_from_dem(const void *dem, int dem_type, double res, double wspe
                           double threshold, double *usable, int rows, int cols,
                           void *stream);
 
+/* Wind preparation of snapshot / seasonal modes (ssrs/simulator.py:778-792):
+ * `batch` sets of speed/direction samples on a regular nx x ny lattice (origin
+ * x0,y0 and spacings dx,dy in the raster's length unit, cell_size likewise;
+ * lattice arrays (batch, ny, nx) f64) -> u/v components -> bilinear
+ * interpolation to cell centres (clamped at the hull) -> per-cell speed and
+ * direction in [0, 360), (batch, rows, cols) f64.  The reference triangulates
+ * scattered points with scipy griddata; on a lattice bilinear is its equivalent. */
+int ssrs_wind_from_lattice(const double *lattice_speed, const double *lattice_dirn,
+                           int nx, int ny, double x0, double y0, double dx, double dy,
+                           double cell_size, double *wspeed, double *wdirn, int rows,
+                           int cols, int batch, void *stream);
+
+/* compute_thermals (ssrs/layers.py:188-214), split in its two stages.
+ * ssrs_thermal_seeds: per-cell seeding inside the 10 % border with probability
+ * 1/(int(wt)-1), wt = 1000 + |aspect-180|/180*2000, amplitude
+ * lognormal(scale + 3, 0.5); counter-based (Philox keyed by seed and cell) --
+ * statistical parity only, the reference replays a serial global RNG.
+ * ssrs_gaussian_blur: scipy.ndimage.gaussian_filter(sigma, mode='constant'),
+ * separable, truncated at 4 sigma.  thermals = blur(seeds, sigma = 4). */
+int ssrs_thermal_seeds(const double *aspect, double thermal_intensity_scale,
+                       uint64_t seed, double *seeds, int rows, int cols, void *stream);
+size_t ssrs_blur_workspace_bytes(int rows, int cols, double sigma);
+int ssrs_gaussian_blur(const double *in, double *out, double sigma, int rows, int cols,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
 /* ----------------------------------------------------------------- stepper */
 
 /* Per-run constants of generate_simulated_tracks (ssrs/movmodel.py:264-318).

@@ -19,7 +19,8 @@ SSRS_TRACKS_NO_SCHEDULE = 4
 EXPORTS = (
     'ssrs_version', 'ssrs_last_error', 'ssrs_device_info', 'ssrs_slope_aspect',
     'ssrs_orographic_updraft', 'ssrs_threshold_updraft', 'ssrs_updraft_from_dem',
-    'ssrs_track_params_init', 'ssrs_transition_table_build',
+    'ssrs_wind_from_lattice', 'ssrs_thermal_seeds', 'ssrs_blur_workspace_bytes',
+    'ssrs_gaussian_blur', 'ssrs_track_params_init', 'ssrs_transition_table_build',
     'ssrs_tracks_workspace_bytes', 'ssrs_tracks_simulate', 'ssrs_uniform_selftest',
     'ssrs_presence_count', 'ssrs_presence_workspace_bytes', 'ssrs_presence_smooth',
     'ssrs_presence_normalise_add', 'ssrs_presence_normalise_f32',
@@ -69,6 +70,9 @@ def lib():
         if hasattr(L, 'ssrs_presence_workspace_bytes'):
             L.ssrs_presence_workspace_bytes.restype = C.c_size_t
             L.ssrs_presence_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
+        if hasattr(L, 'ssrs_blur_workspace_bytes'):
+            L.ssrs_blur_workspace_bytes.restype = C.c_size_t
+            L.ssrs_blur_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_double]
         if hasattr(L, 'ssrs_potential_workspace_bytes'):
             L.ssrs_potential_workspace_bytes.restype = C.c_size_t
             L.ssrs_potential_workspace_bytes.argtypes = [C.c_int, C.c_int]

@@ -7,7 +7,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
-SOURCES = ['capi.hip', 'raster.hip', 'tracks.hip', 'presence.hip', 'potential.hip']
+SOURCES = ['capi.hip', 'raster.hip', 'tracks.hip', 'presence.hip', 'potential.hip', 'thermals.hip']
 LIB = os.path.join(PKG, 'libssrs_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
          '-fno-fast-math', '-fgpu-rdc=0' if False else '-Wall', '-Wno-unused-function']

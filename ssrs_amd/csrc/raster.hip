@@ -407,3 +407,75 @@ extern "C" int ssrs_threshold_updraft(const float *in, double threshold, double 
     SSRS_HIP_CHECK(hipGetLastError());
     return SSRS_OK;
 }
+
+// ---------------------------------------------------------------------------
+// K6 -- wind field preparation for snapshot / seasonal modes
+// (ssrs/simulator.py:778-792): speed/direction samples -> easterly/northerly
+// components -> interpolation to the terrain grid -> speed and direction
+// (degrees in [0, 360)).  The reference interpolates scattered WTK points with
+// scipy griddata (Qhull Delaunay, 'linear'); on a regular lattice -- the shape
+// of the 2-km WTK grid and of the synthetic configs -- piecewise-bilinear
+// interpolation is the natural equivalent and needs no triangulation.  The
+// lattice (<= a few thousand points) is read through L2; one thread per cell.
+namespace ssrs {
+
+__global__ __launch_bounds__(kBlock) void k_wind_lattice(
+    const double *__restrict__ lat_speed, const double *__restrict__ lat_dirn, int nx, int ny,
+    double x0, double y0, double dx, double dy, double cell, double *__restrict__ wspeed,
+    double *__restrict__ wdirn, int rows, int cols, int batch)
+{
+    const size_t ncell = static_cast<size_t>(rows) * cols;
+    const size_t total = ncell * batch;
+    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < total;
+         i += static_cast<size_t>(gridDim.x) * kBlock) {
+        const int b = static_cast<int>(i / ncell);
+        const size_t c0 = i - static_cast<size_t>(b) * ncell;
+        const int r = static_cast<int>(c0 / cols), c = static_cast<int>(c0 % cols);
+        // cell centre in lattice units, clamped to the lattice hull
+        double fx = (c * cell - x0) / dx, fy = (r * cell - y0) / dy;
+        fx = fx < 0.0 ? 0.0 : (fx > nx - 1.0 ? nx - 1.0 : fx);
+        fy = fy < 0.0 ? 0.0 : (fy > ny - 1.0 ? ny - 1.0 : fy);
+        int ix = static_cast<int>(fx), iy = static_cast<int>(fy);
+        ix = ix > nx - 2 ? (nx > 1 ? nx - 2 : 0) : ix;
+        iy = iy > ny - 2 ? (ny > 1 ? ny - 2 : 0) : iy;
+        const double tx = nx > 1 ? fx - ix : 0.0, ty = ny > 1 ? fy - iy : 0.0;
+        const double *ls = lat_speed + static_cast<size_t>(b) * nx * ny;
+        const double *ld = lat_dirn + static_cast<size_t>(b) * nx * ny;
+        double east = 0.0, north = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int jx = ix + (k & 1 && nx > 1 ? 1 : 0), jy = iy + (k >> 1 && ny > 1 ? 1 : 0);
+            const double w = ((k & 1) ? tx : 1.0 - tx) * ((k >> 1) ? ty : 1.0 - ty);
+            const double s = ls[static_cast<size_t>(jy) * nx + jx];
+            const double a = ld[static_cast<size_t>(jy) * nx + jx] * kPi / 180.0;
+            east += w * (s * sin(a));       // simulator.py:784
+            north += w * (s * cos(a));      // simulator.py:785
+        }
+        const double spd = sqrt(east * east + north * north);
+        double ang = atan2(east, north);                               // :790
+        ang = fmod(ang + 2.0 * kPi, 2.0 * kPi);                        // :791
+        wspeed[i] = spd;
+        wdirn[i] = ang * 180.0 / kPi;
+    }
+}
+
+}  // namespace ssrs
+
+extern "C" int ssrs_wind_from_lattice(const double *lattice_speed, const double *lattice_dirn,
+                                      int nx, int ny, double x0, double y0, double dx, double dy,
+                                      double cell_size, double *wspeed, double *wdirn, int rows,
+                                      int cols, int batch, void *stream)
+{
+    SSRS_REQUIRE(lattice_speed && lattice_dirn && wspeed && wdirn,
+                 "ssrs_wind_from_lattice: NULL pointer");
+    SSRS_REQUIRE(nx >= 1 && ny >= 1 && rows > 0 && cols > 0 && batch > 0,
+                 "ssrs_wind_from_lattice: bad sizes");
+    SSRS_REQUIRE(dx > 0.0 && dy > 0.0 && cell_size > 0.0,
+                 "ssrs_wind_from_lattice: spacings must be > 0");
+    const size_t total = static_cast<size_t>(rows) * cols * batch;
+    hipLaunchKernelGGL(k_wind_lattice, dim3(stream_grid(total)), dim3(kBlock), 0,
+                       as_stream(stream), lattice_speed, lattice_dirn, nx, ny, x0, y0, dx, dy,
+                       cell_size, wspeed, wdirn, rows, cols, batch);
+    SSRS_HIP_CHECK(hipGetLastError());
+    return SSRS_OK;
+}

@@ -159,3 +159,64 @@ def test_raster_c2_size_properties(gpu):
     oro_half, _ = layers.updraft_from_dem(dem, 10., 5., 270.)
     assert torch.allclose(oro_half * 2, oro, rtol=3e-7, atol=0)   # linear in wspeed
     assert float(oro.min()) >= 0.0 and bool((oro[0] == 0).all()) and bool((oro[:, 0] == 0).all())
+
+
+def test_wind_lattice_interpolation_vs_oracle(gpu):
+    """K6: u/v bilinear interpolation of a WTK-shaped lattice (simulator.py:778-792)."""
+    from ssrs_amd.wind import interpolate_wind_lattice
+    from ssrs_amd.synthetic import wind_lattice
+    from oracle import ssrs_oracle as orc
+    from scipy.interpolate import RegularGridInterpolator
+    rows, cols, res = 120, 150, 100.
+    x, y, ws, wd = wind_lattice((cols * res / 1000., rows * res / 1000.), 2.0, phase=0.3)
+    xs = np.arange(cols) * res / 1000.
+    ys = np.arange(rows) * res / 1000.
+    pts = np.stack(np.meshgrid(np.clip(ys, y[0], y[-1]), np.clip(xs, x[0], x[-1]), indexing='ij'), -1)
+
+    def interp(vals):
+        return RegularGridInterpolator((y, x), vals.reshape(y.size, x.size))(pts)
+    ref_s, ref_d = orc.interpolate_wind_uv(ws, wd, interp)
+    got_s, got_d = interpolate_wind_lattice(x, y, ws, wd, (rows, cols), res)
+    np.testing.assert_allclose(got_s.cpu().numpy(), ref_s, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(got_d.cpu().numpy(), ref_d, rtol=1e-12, atol=1e-10)
+    assert float(got_d.min()) >= 0.0 and float(got_d.max()) < 360.0
+    # batched (seasonal) call == per-snapshot calls
+    phases = [0.0, 1.0, 2.0]
+    lat = [wind_lattice((cols * res / 1000., rows * res / 1000.), 2.0, phase=p) for p in phases]
+    bs, bd = interpolate_wind_lattice(x, y, np.stack([l[2] for l in lat]),
+                                      np.stack([l[3] for l in lat]), (rows, cols), res)
+    for i, l in enumerate(lat):
+        s1, d1 = interpolate_wind_lattice(x, y, l[2], l[3], (rows, cols), res)
+        assert torch.equal(bs[i], s1) and torch.equal(bd[i], d1)
+
+
+def test_thermals_blur_exact_and_seeding_statistics(gpu):
+    """a5 (layers.py:188-214): the Gaussian blur equals scipy's on the same seed
+    field; the seeding is checked statistically (the reference replays a serial
+    global RNG: only statistical parity exists)."""
+    from scipy import ndimage
+    from ssrs_amd import thermals
+    rng = np.random.default_rng(4)
+    field = (rng.random((90, 130)) < 0.01) * rng.lognormal(5., 0.5, size=(90, 130))
+    got = thermals.gaussian_blur(field, 4.0)
+    np.testing.assert_allclose(got, ndimage.gaussian_filter(field, sigma=4, mode='constant'),
+                               rtol=1e-12, atol=1e-12)
+    rows, cols = 1000, 1200
+    aspect = rng.uniform(0., 360., (rows, cols))
+    seeds = thermals.thermal_seeds(aspect, 2.0, seed=11)
+    by, bx = int(0.1 * rows), int(0.1 * cols)
+    assert (seeds[:by] == 0).all() and (seeds[-by:] == 0).all()
+    assert (seeds[:, :bx] == 0).all() and (seeds[:, -bx:] == 0).all()
+    inner = seeds[by:rows - by, bx:cols - bx]
+    wt = 1000. + np.abs(aspect[by:rows - by, bx:cols - bx] - 180.) / 180. * 2000.
+    expect = (1. / (wt.astype(int) - 1)).sum()             # expected number of seeded cells
+    n = int((inner > 0).sum())
+    assert abs(n - expect) < 5 * np.sqrt(expect), (n, expect)
+    logs = np.log(inner[inner > 0])
+    assert abs(logs.mean() - 5.0) < 5 * 0.5 / np.sqrt(n) and abs(logs.std() - 0.5) < 0.1
+    # reproducible per seed, different across seeds
+    assert np.array_equal(seeds, thermals.thermal_seeds(aspect, 2.0, seed=11))
+    assert not np.array_equal(seeds, thermals.thermal_seeds(aspect, 2.0, seed=12))
+    th = thermals.compute_thermals(aspect, 2.0, seed=11)
+    np.testing.assert_allclose(th, ndimage.gaussian_filter(seeds, sigma=4, mode='constant'),
+                               rtol=1e-12, atol=1e-12)

@@ -112,3 +112,40 @@ def test_constructor_errors(tmp_path):
         Simulator(make_config(tmp_path, run_name='e1'))
     with pytest.raises(ValueError):
         Simulator(make_config(tmp_path, run_name='e2'), terrain=np.zeros((3, 3)))
+
+
+def test_seasonal_mode_lattice_wind_and_thermals(gpu, tmp_path):
+    """Seasonal mode: several injected WTK-shaped lattice snapshots (K6) batched
+    through K1, plus one thermal realisation per case (a5): file contract of
+    simulator.py:200-228 and the [orograph] + [orograph + thermals] updraft list."""
+    from ssrs_amd import Simulator
+    from ssrs_amd.synthetic import wind_lattice
+    from ssrs_amd.wind import interpolate_wind_lattice
+    from oracle import ssrs_oracle as orc
+    cfg = make_config(tmp_path, sim_mode='seasonal', run_name='seas', track_count=40,
+                      thermals_realization_count=1, movement_model='drw')
+    wind = []
+    for s in range(3):
+        x, y, ws, wd = wind_lattice((8., 6.), 2.0, phase=2 * np.pi * s / 3)
+        wind.append(dict(datetime=(2010, 4, 1 + s, 12), x_km=x, y_km=y, wspeed=ws, wdirn=wd))
+    sim = Simulator(cfg, terrain='synthetic', wind=wind)
+    assert sim.case_ids == ['y2010m04d01h12', 'y2010m04d02h12', 'y2010m04d03h12']
+    dem = sim.get_terrain_elevation()
+    slope, aspect = orc.compute_slope_degrees(dem, 100.), orc.compute_aspect_degrees(dem, 100.)
+    for item, cid in zip(wind, sim.case_ids):
+        s, d = interpolate_wind_lattice(item['x_km'], item['y_km'], item['wspeed'], item['wdirn'],
+                                        (60, 80), 100.)
+        ref = orc.compute_orographic_updraft(s.cpu().numpy(), d.cpu().numpy(), slope, aspect)
+        oro = np.load(os.path.join(sim.mode_data_dir, f'{cid}_orograph.npy'))
+        dd = np.abs(oro.view(np.int32).astype(np.int64) - ref.astype(np.float32).view(np.int32))
+        assert dd.max() <= 1
+        th = np.load(os.path.join(sim.mode_data_dir, f'{cid}_r0_thermals.npy'))
+        assert th.dtype == np.float32 and th.shape == (60, 80) and th.min() >= 0
+    ups = sim.load_updrafts(sim.case_ids[0])
+    assert len(ups) == 2 and ups[0].dtype == np.float64
+    sim.simulate_tracks()                       # 3 cases x 2 realisations
+    for cid in sim.case_ids:
+        for real in (0, 1):
+            assert os.path.exists(os.path.join(sim.mode_data_dir, f'{cid}_d0_t75_drw_r{real}_tracks.pkl'))
+    out = sim.compute_presence_map(radius=300.)
+    assert out.shape == (60, 80) and out.max() == 1.0
