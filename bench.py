@@ -47,6 +47,7 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=20.0,
                     help='target CPU time of the cpu_baseline sample (0 = skip)')
     ap.add_argument('--potential', default='ramp', choices=['ramp', 'solve'])
+    ap.add_argument('--no-binning', action='store_true', help='per-step global atomics for the histogram')
     ap.add_argument('--no-schedule', action='store_true', help='disable the coherent schedule')
     ap.add_argument('--exact-only', action='store_true', help='disable the fast decision path')
     return ap.parse_args()
@@ -139,7 +140,7 @@ def main():
 
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     acc = dict(raster_ms=0.0, table_ms=0.0, step_kernel_ms=0.0, step_wall_ms=0.0,
-               steps=0, launches=0)
+               hist_ms=0.0, steps=0, launches=0)
 
     def one_step(timed):
         hist.zero_()
@@ -152,7 +153,7 @@ def main():
                                        track_id_base=lo, table=table, use_table=not args.direct,
                                        hist=hist, steps_per_launch=args.steps_per_launch,
                                        profile=True, exact_only=args.exact_only,
-                                       schedule=not args.no_schedule)
+                                       schedule=not args.no_schedule, binning=not args.no_binning)
         reduce_histogram(hist, dst=0)
         ev[3].record()
         if timed:
@@ -161,6 +162,7 @@ def main():
             acc['table_ms'] += ev[1].elapsed_time(ev[2])
             acc['step_kernel_ms'] += out.stats['kernel_ms']
             acc['step_wall_ms'] += out.stats['wall_ms']
+            acc['hist_ms'] += out.stats['hist_ms']
             acc['steps'] += out.stats['total_steps']
             acc['launches'] += out.stats['launches']
         return out
@@ -229,6 +231,7 @@ def main():
         'phase_ms_per_step': {
             'raster_k1': acc['raster_ms'] / K, 'table_k2a': acc['table_ms'] / K,
             'stepper_kernels_k2b': acc['step_kernel_ms'] / K,
+            'histogram_binning_k3': acc['hist_ms'] / K,
             'stepper_wall': acc['step_wall_ms'] / K,
         },
         'roofline': {

@@ -139,14 +139,17 @@ typedef struct SsrsTrackParams {
 #define SSRS_TRACKS_PROFILE 1    /* time every launch with HIP events (stats) */
 #define SSRS_TRACKS_NO_SCHEDULE 4 /* keep caller order, release every track at once
                                     (A/B switch for the coherent schedule) */
+#define SSRS_TRACKS_NO_BINNING 8  /* histogram by per-step global atomics instead of the
+                                    visit buffer + LDS binning kernel (A/B switch) */
 #define SSRS_TRACKS_EXACT_ONLY 2 /* disable the guarded division-free decision
                                    (A/B switch; results are identical) */
 
 typedef struct SsrsTrackStats {
     int64_t total_steps; /* moves taken by all tracks of this call */
     int32_t launches;    /* stepper kernel launches */
-    float kernel_ms;     /* sum of launch durations (SSRS_TRACKS_PROFILE) */
+    float kernel_ms;     /* sum of stepper launch durations (SSRS_TRACKS_PROFILE) */
     float wall_ms;       /* first launch -> last completion, HIP events */
+    float hist_ms;       /* sum of histogram-binning launch durations (PROFILE) */
 } SsrsTrackStats;
 
 /* Fills rows/cols/burnin/max_moves/memory/nu and zeroes the rest; `prior` must
@@ -228,14 +231,23 @@ typedef struct SsrsSolveStats {
     int32_t converged; /* 1 when |r| <= rel_tol |b| was reached */
     double residual;   /* final |r| / |b| */
     float kernel_ms;
+    int32_t amg_levels;   /* levels of the aggregation hierarchy (0 = none) */
+    int32_t amg_coarsest; /* nodes on its last level */
 } SsrsSolveStats;
+
+#define SSRS_SOLVE_NO_AMG 1  /* plain BiCGStab (A/B switch; stalls on real rasters) */
+#define SSRS_SOLVE_K_CYCLE 2 /* K-cycle on the first three coarse levels instead of
+                               the V-cycle (experimental: costs 5x per iteration and
+                               has not reduced the iteration count so far) */
 
 size_t ssrs_potential_workspace_bytes(int rows, int cols);
 
 /* MovModel.assemble_sparse_linear_system + solve_sparse_linear_system
  * (ssrs/movmodel.py:59-128) without assembling anything: the row-normalised
  * 8-neighbour conductance operator is applied matrix-free and the Dirichlet
- * problem is solved iteratively in f64 (the reference factorises with SuperLU).
+ * problem is solved in f64 by BiCGStab, right-preconditioned with one V-cycle of
+ * an aggregation AMG built on the device from the same conductances (the
+ * reference factorises with SuperLU).
  *   conductivity  f64 (rows, cols): the usable updraft
  *   fixed_mask    u8  (rows, cols): 1 on Dirichlet cells (get_boundary_nodes,
  *                 movmodel.py:21-57, evaluated by the host)
@@ -245,7 +257,8 @@ size_t ssrs_potential_workspace_bytes(int rows, int cols);
 int ssrs_potential_solve(const double *conductivity, const uint8_t *fixed_mask,
                          const double *fixed_values, const double *initial_guess,
                          float *potential, int rows, int cols, double rel_tol,
-                         int max_iterations, void *workspace, size_t workspace_bytes,
+                         int max_iterations, int flags, void *workspace,
+                         size_t workspace_bytes,
                          void *stats /* SsrsSolveStats*, [host], may be NULL */,
                          void *stream);
 

@@ -15,6 +15,8 @@ SSRS_OK, SSRS_ERR_INVALID, SSRS_ERR_HIP, SSRS_ERR_START = 0, -1, -2, -3
 SSRS_TRACKS_PROFILE = 1
 SSRS_TRACKS_EXACT_ONLY = 2
 SSRS_TRACKS_NO_SCHEDULE = 4
+SSRS_TRACKS_NO_BINNING = 8
+SSRS_SOLVE_NO_AMG = 1
 
 EXPORTS = (
     'ssrs_version', 'ssrs_last_error', 'ssrs_device_info', 'ssrs_slope_aspect',
@@ -37,12 +39,13 @@ class SsrsTrackParams(C.Structure):
 
 class SsrsTrackStats(C.Structure):
     _fields_ = [('total_steps', C.c_int64), ('launches', C.c_int32),
-                ('kernel_ms', C.c_float), ('wall_ms', C.c_float)]
+                ('kernel_ms', C.c_float), ('wall_ms', C.c_float), ('hist_ms', C.c_float)]
 
 
 class SsrsSolveStats(C.Structure):
     _fields_ = [('iterations', C.c_int32), ('converged', C.c_int32),
-                ('residual', C.c_double), ('kernel_ms', C.c_float)]
+                ('residual', C.c_double), ('kernel_ms', C.c_float),
+                ('amg_levels', C.c_int32), ('amg_coarsest', C.c_int32)]
 
 
 class SsrsError(RuntimeError):

@@ -1,0 +1,814 @@
+// K5 preconditioner -- aggregation algebraic multigrid for the potential system.
+//
+// Why: the fluid-flow operator of ssrs/movmodel.py:87-128 links cells by the
+// harmonic mean of their updrafts, which spans ten orders of magnitude (1e-8
+// for zero-updraft cells, 2e-10 .. 5 elsewhere).  Conductive clusters that float
+// in dead terrain give eigenvalues ~1e-8; Krylov methods without a coarse space
+// stall (DESIGN.md "K5").  Geometric coarsening fails for the same reason
+// (tools/amg_experiment2.py); aggregation along the STRONG couplings works
+// (tools/amg_experiment4.py) because a floating cluster collapses into few
+// coarse nodes whose level the coarse problem determines directly.
+//
+// Method (all on the device, deterministic -- no float atomics):
+//   level 0   CSR of the symmetric operator L = D - C on the raster numbering
+//             (Dirichlet cells = isolated identity rows), natural 8-neighbour
+//             weights (the reference's east-edge quirk lives only in the outer
+//             Krylov operator, potential.hip)
+//   coarsen   pairwise aggregation: every unmatched node proposes to its
+//             strongest unmatched neighbour (>= 0.25 of the row maximum, ties
+//             broken by a symmetric hash), mutual proposals pair up, 8 rounds;
+//             leftover nodes may join an adjacent pair (the pair keeps the
+//             highest-priority applicant: atomicMax, order independent)
+//   Galerkin  P^T A P by radix-sorting (I,J) keys + reduce-by-key (hipCUB)
+//   cycle     V(2,2), damped Jacobi (omega 0.7), dense inverse on the coarsest
+//             level (<= 1024 nodes, Gauss-Jordan on the device)
+#include <hipcub/hipcub.hpp>
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "amg.h"
+
+namespace ssrs {
+
+namespace {
+
+constexpr double kOmega = 0.7;
+constexpr double kTheta = 0.25;
+constexpr int kMatchRounds = 8;
+constexpr int kMaxDense = 1024;
+
+struct Bump {
+    char *base;
+    size_t cap, off;
+    void *take(size_t bytes)
+    {
+        const size_t a = (off + 255) / 256 * 256;
+        if (a + bytes > cap) return nullptr;
+        off = a + bytes;
+        return base + a;
+    }
+};
+
+inline int grid_for(size_t n)
+{
+    size_t b = (n + kBlock - 1) / kBlock;
+    if (b < 1) b = 1;
+    if (b > (1u << 20)) b = 1u << 20;
+    return static_cast<int>(b);
+}
+
+__device__ __forceinline__ double pair_weight(double a, double b)
+{
+    return (a != 0.0 && b != 0.0) ? 2.0 / (1.0 / a + 1.0 / b) : 1e-08;
+}
+
+// ---- level 0 from the raster ------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_l0_count(const uint8_t *__restrict__ fixed, int rows,
+                                                    int cols, int *__restrict__ cnt)
+{
+    const size_t n = static_cast<size_t>(rows) * cols;
+    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * kBlock) {
+        int c = 1;
+        if (!fixed[i]) {
+            const int r = static_cast<int>(i / cols), cc = static_cast<int>(i % cols);
+            for (int dr = -1; dr <= 1; ++dr)
+                for (int dc = -1; dc <= 1; ++dc) {
+                    if (!dr && !dc) continue;
+                    const int rr = r + dr, c2 = cc + dc;
+                    if (rr < 0 || rr >= rows || c2 < 0 || c2 >= cols) continue;
+                    if (!fixed[static_cast<size_t>(rr) * cols + c2]) ++c;
+                }
+        }
+        cnt[i] = c;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_l0_fill(const double *__restrict__ cond,
+                                                   const uint8_t *__restrict__ fixed, int rows,
+                                                   int cols, const int *__restrict__ rowptr,
+                                                   int *__restrict__ col, double *__restrict__ val)
+{
+    const size_t n = static_cast<size_t>(rows) * cols;
+    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * kBlock) {
+        int p = rowptr[i];
+        if (fixed[i]) {
+            col[p] = static_cast<int>(i);
+            val[p] = 1.0;
+            continue;
+        }
+        const int r = static_cast<int>(i / cols), cc = static_cast<int>(i % cols);
+        const double ci = cond[i];
+        double diag = 0.0;
+        const int pd = p++;                       // diagonal first
+        for (int dr = -1; dr <= 1; ++dr)
+            for (int dc = -1; dc <= 1; ++dc) {
+                if (!dr && !dc) continue;
+                const int rr = r + dr, c2 = cc + dc;
+                if (rr < 0 || rr >= rows || c2 < 0 || c2 >= cols) continue;
+                const size_t j = static_cast<size_t>(rr) * cols + c2;
+                double w = pair_weight(ci, cond[j]);
+                if (dr && dc) w = w / 1.41421353816986083984375;
+                diag += w;
+                if (!fixed[j]) {
+                    col[p] = static_cast<int>(j);
+                    val[p] = -w;
+                    ++p;
+                }
+            }
+        col[pd] = static_cast<int>(i);
+        val[pd] = diag;
+    }
+}
+
+// ---- per-level helpers --------------------------------------------------------
+// dinv = omega-compensated inverse diagonal; isolated rows are solved exactly
+__global__ __launch_bounds__(kBlock) void k_dinv(const int *__restrict__ rowptr,
+                                                const int *__restrict__ col,
+                                                const double *__restrict__ val, int n,
+                                                double *__restrict__ dinv)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        double d = 1.0;
+        for (int p = rowptr[i]; p < rowptr[i + 1]; ++p)
+            if (col[p] == i) d = val[p];
+        const bool isolated = rowptr[i + 1] - rowptr[i] <= 1;
+        dinv[i] = (isolated ? 1.0 / kOmega : 1.0) / d;
+    }
+}
+
+__device__ __forceinline__ uint32_t edge_hash(uint32_t a, uint32_t b)
+{
+    const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+    uint32_t h = lo * 0x9E3779B1u ^ (hi + 0x7F4A7C15u) * 0x85EBCA6Bu;
+    h ^= h >> 15; h *= 0xC2B2AE35u; h ^= h >> 13;
+    return h;
+}
+
+__device__ __forceinline__ unsigned long long edge_priority(double w, uint32_t i, uint32_t j)
+{   // positive doubles order like their bit patterns; the low 20 mantissa bits
+    // are replaced by a symmetric hash so that equal weights tie-break randomly
+    unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(w));
+    return (b & ~0xFFFFFull) | (edge_hash(i, j) & 0xFFFFFu);
+}
+
+// every unmatched node proposes to its best unmatched strong neighbour
+__global__ __launch_bounds__(kBlock) void k_propose(const int *__restrict__ rowptr,
+                                                   const int *__restrict__ col,
+                                                   const double *__restrict__ val, int n,
+                                                   const int *__restrict__ match,
+                                                   int *__restrict__ prop, double theta)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        int best = -1;
+        if (match[i] < 0) {
+            double wmax = 0.0;
+            for (int p = rowptr[i]; p < rowptr[i + 1]; ++p)
+                if (col[p] != i && -val[p] > wmax) wmax = -val[p];
+            unsigned long long bp = 0;
+            for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) {
+                const int j = col[p];
+                const double w = -val[p];
+                if (j == i || !(w > 0.0) || w < theta * wmax || match[j] >= 0) continue;
+                const unsigned long long pr = edge_priority(w, i, j);
+                if (pr > bp) { bp = pr; best = j; }
+            }
+        }
+        prop[i] = best;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_accept(int n, const int *__restrict__ prop,
+                                                  int *__restrict__ match)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const int j = prop[i];
+        if (j >= 0 && prop[j] == i) match[i] = j;
+    }
+}
+
+// leftover nodes apply to the pair of their strongest matched neighbour; the
+// pair's leader keeps the best applicant (order-independent atomicMax)
+__global__ __launch_bounds__(kBlock) void k_apply_join(const int *__restrict__ rowptr,
+                                                      const int *__restrict__ col,
+                                                      const double *__restrict__ val, int n,
+                                                      const int *__restrict__ match,
+                                                      unsigned long long *__restrict__ third)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        if (match[i] >= 0 || rowptr[i + 1] - rowptr[i] <= 1) continue;
+        double wmax = 0.0;
+        for (int p = rowptr[i]; p < rowptr[i + 1]; ++p)
+            if (col[p] != i && -val[p] > wmax) wmax = -val[p];
+        unsigned long long bp = 0;
+        int best = -1;
+        for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) {
+            const int j = col[p];
+            const double w = -val[p];
+            if (j == i || !(w > 0.0) || w < kTheta * wmax || match[j] < 0) continue;
+            const unsigned long long pr = edge_priority(w, i, j);
+            if (pr > bp) { bp = pr; best = j; }
+        }
+        if (best >= 0) {
+            const int leader = best < match[best] ? best : match[best];
+            // priority in the high bits, applicant id in the low 32
+            const unsigned long long key = (bp & 0xFFFFFFFF00000000ull) | static_cast<uint32_t>(i);
+            atomicMax(&third[leader], key);
+        }
+    }
+}
+
+// flag = 1 for aggregate leaders (pair leader = smaller index; singles that did
+// not join anyone; isolated rows get no aggregate at all)
+__global__ __launch_bounds__(kBlock) void k_leader_flags(const int *__restrict__ rowptr, int n,
+                                                        const int *__restrict__ match,
+                                                        const unsigned long long *__restrict__ third,
+                                                        int *__restrict__ joined_to,
+                                                        int *__restrict__ flag)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        joined_to[i] = -1;
+        const bool isolated = rowptr[i + 1] - rowptr[i] <= 1;
+        int f = 0;
+        if (!isolated) {
+            if (match[i] >= 0) f = i < match[i] ? 1 : 0;
+            else f = 1;                      // provisional: cleared below if it joined a pair
+        }
+        flag[i] = f;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_resolve_join(int n, const int *__restrict__ match,
+                                                        const unsigned long long *__restrict__ third,
+                                                        int *__restrict__ joined_to,
+                                                        int *__restrict__ flag)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        if (match[i] >= 0 && i < match[i] && third[i] != 0ull) {
+            const int applicant = static_cast<int>(third[i] & 0xFFFFFFFFull);
+            joined_to[applicant] = i;
+            flag[applicant] = 0;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_assign_agg(const int *__restrict__ rowptr, int n,
+                                                      const int *__restrict__ match,
+                                                      const int *__restrict__ joined_to,
+                                                      const int *__restrict__ flag,
+                                                      const int *__restrict__ cid,   // exclusive scan of flag
+                                                      int *__restrict__ agg, int *__restrict__ members)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const bool isolated = rowptr[i + 1] - rowptr[i] <= 1;
+        int a = -1;
+        if (!isolated) {
+            int leader = i;
+            if (match[i] >= 0) leader = i < match[i] ? i : match[i];
+            else if (joined_to[i] >= 0) leader = joined_to[i];
+            a = cid[leader];
+            if (flag[i]) {                                   // leader writes the member list
+                members[3 * a + 0] = i;
+                members[3 * a + 1] = match[i] >= 0 ? match[i] : -1;
+                members[3 * a + 2] = -1;
+            }
+        }
+        agg[i] = a;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_third_member(int n, const int *__restrict__ joined_to,
+                                                        const int *__restrict__ agg,
+                                                        int *__restrict__ members)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+        if (joined_to[i] >= 0) members[3 * agg[i] + 2] = i;
+}
+
+// Galerkin keys: one (I, J) key per fine entry whose ends both have aggregates
+__global__ __launch_bounds__(kBlock) void k_galerkin_keys(const int *__restrict__ rowptr,
+                                                         const int *__restrict__ col,
+                                                         const double *__restrict__ val, int n,
+                                                         const int *__restrict__ agg,
+                                                         unsigned long long *__restrict__ keys,
+                                                         double *__restrict__ vals)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const int I = agg[i];
+        for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) {
+            const int J = agg[col[p]];
+            // entries to/from nodes without aggregate are parked behind all real keys
+            const bool ok = I >= 0 && J >= 0;
+            keys[p] = ok ? (static_cast<unsigned long long>(I) << 32) | static_cast<uint32_t>(J)
+                         : ~0ull;
+            vals[p] = ok ? val[p] : 0.0;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_unpack_coarse(const unsigned long long *__restrict__ keys,
+                                                         int nnz, int nc, int *__restrict__ rowptr,
+                                                         int *__restrict__ col)
+{
+    for (int e = blockIdx.x * kBlock + threadIdx.x; e < nnz; e += gridDim.x * kBlock) {
+        const int I = static_cast<int>(keys[e] >> 32);
+        col[e] = static_cast<int>(keys[e] & 0xFFFFFFFFull);
+        if (e == 0 || static_cast<int>(keys[e - 1] >> 32) != I) rowptr[I] = e;
+        if (e == nnz - 1) rowptr[nc] = nnz;
+    }
+}
+
+// ---- cycle kernels --------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_jacobi_first(const double *__restrict__ dinv,
+                                                        const double *__restrict__ b, int n,
+                                                        double *__restrict__ x)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+        x[i] = kOmega * dinv[i] * b[i];
+}
+
+__global__ __launch_bounds__(kBlock) void k_jacobi(const int *__restrict__ rowptr,
+                                                  const int *__restrict__ col,
+                                                  const double *__restrict__ val,
+                                                  const double *__restrict__ dinv,
+                                                  const double *__restrict__ b,
+                                                  const double *__restrict__ x, int n,
+                                                  double *__restrict__ xn)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        double ax = 0.0;
+        for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) ax += val[p] * x[col[p]];
+        xn[i] = x[i] + kOmega * dinv[i] * (b[i] - ax);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_residual(const int *__restrict__ rowptr,
+                                                    const int *__restrict__ col,
+                                                    const double *__restrict__ val,
+                                                    const double *__restrict__ b,
+                                                    const double *__restrict__ x, int n,
+                                                    double *__restrict__ r)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        double ax = 0.0;
+        for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) ax += val[p] * x[col[p]];
+        r[i] = b[i] - ax;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_restrict(const int *__restrict__ members,
+                                                    const double *__restrict__ r, int nc,
+                                                    double *__restrict__ bc)
+{
+    for (int I = blockIdx.x * kBlock + threadIdx.x; I < nc; I += gridDim.x * kBlock) {
+        double s = r[members[3 * I]];
+        const int m1 = members[3 * I + 1], m2 = members[3 * I + 2];
+        if (m1 >= 0) s += r[m1];
+        if (m2 >= 0) s += r[m2];
+        bc[I] = s;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_prolong_add(const int *__restrict__ agg,
+                                                       const double *__restrict__ xc, int n,
+                                                       double *__restrict__ x)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const int a = agg[i];
+        if (a >= 0) x[i] += xc[a];
+    }
+}
+
+// ---- dense coarsest level ---------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_dense_fill(const int *__restrict__ rowptr,
+                                                      const int *__restrict__ col,
+                                                      const double *__restrict__ val, int n,
+                                                      double *__restrict__ aug)   // n x 2n [A | I]
+{
+    const size_t total = static_cast<size_t>(n) * 2 * n;
+    for (size_t e = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; e < total;
+         e += static_cast<size_t>(gridDim.x) * kBlock) {
+        const int i = static_cast<int>(e / (2 * n)), j = static_cast<int>(e % (2 * n));
+        aug[e] = (j >= n && j - n == i) ? 1.0 : 0.0;
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_dense_scatter(const int *__restrict__ rowptr,
+                                                         const int *__restrict__ col,
+                                                         const double *__restrict__ val, int n,
+                                                         double *__restrict__ aug)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+        for (int p = rowptr[i]; p < rowptr[i + 1]; ++p)
+            aug[static_cast<size_t>(i) * 2 * n + col[p]] = val[p];
+}
+// Gauss-Jordan step k: rows i != k get row_i -= (a_ik / a_kk) row_k; the pivot
+// column is saved first so that the update is race free
+__global__ __launch_bounds__(kBlock) void k_gj_save(const double *__restrict__ aug, int n, int k,
+                                                   double *__restrict__ colk)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+        colk[i] = aug[static_cast<size_t>(i) * 2 * n + k];
+}
+__global__ __launch_bounds__(kBlock) void k_gj_elim(double *__restrict__ aug, int n, int k,
+                                                   const double *__restrict__ colk)
+{
+    const size_t total = static_cast<size_t>(n) * 2 * n;
+    const double piv = colk[k];
+    for (size_t e = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; e < total;
+         e += static_cast<size_t>(gridDim.x) * kBlock) {
+        const int i = static_cast<int>(e / (2 * n)), j = static_cast<int>(e % (2 * n));
+        if (i == k) continue;
+        aug[e] -= (colk[i] / piv) * aug[static_cast<size_t>(k) * 2 * n + j];
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_gj_finish(const double *__restrict__ aug, int n,
+                                                     double *__restrict__ inv)
+{
+    const size_t total = static_cast<size_t>(n) * n;
+    for (size_t e = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; e < total;
+         e += static_cast<size_t>(gridDim.x) * kBlock) {
+        const int i = static_cast<int>(e / n), j = static_cast<int>(e % n);
+        inv[e] = aug[static_cast<size_t>(i) * 2 * n + n + j] / aug[static_cast<size_t>(i) * 2 * n + i];
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_dense_apply(const double *__restrict__ inv,
+                                                       const double *__restrict__ b, int n,
+                                                       double *__restrict__ x)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        double s = 0.0;
+        for (int j = 0; j < n; ++j) s += inv[static_cast<size_t>(i) * n + j] * b[j];
+        x[i] = s;
+    }
+}
+
+__global__ void k_copy(const double *__restrict__ a, double *__restrict__ b, size_t n)
+{
+    for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * blockDim.x)
+        b[i] = a[i];
+}
+
+// ---- K-cycle (Notay): two flexible-CG steps on a coarse level, each
+// preconditioned by the cycle below it; all scalars stay on the device.
+struct KScalars {
+    double rho1, alpha1, gamma, beta, alpha2, f1, f2;
+    double part[3][256];
+};
+
+__global__ __launch_bounds__(kBlock) void k_spmv(const int *__restrict__ rowptr,
+                                                const int *__restrict__ col,
+                                                const double *__restrict__ val,
+                                                const double *__restrict__ x, int n,
+                                                double *__restrict__ y)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        double ax = 0.0;
+        for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) ax += val[p] * x[col[p]];
+        y[i] = ax;
+    }
+}
+
+__device__ __forceinline__ double kblock_sum(double v, double *lds)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+    if (threadIdx.x == 0)
+        for (int w = 0; w < kBlock / 64; ++w) s += lds[w];
+    __syncthreads();
+    return s;
+}
+
+// up to three dot products a_k . b_k in one pass (NULL pairs are skipped)
+__global__ __launch_bounds__(kBlock) void k_dots(const double *a0, const double *b0,
+                                                const double *a1, const double *b1,
+                                                const double *a2, const double *b2, int n,
+                                                KScalars *s)
+{
+    __shared__ double lds[kBlock / 64];
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        d0 += a0[i] * b0[i];
+        if (a1) d1 += a1[i] * b1[i];
+        if (a2) d2 += a2[i] * b2[i];
+    }
+    d0 = kblock_sum(d0, lds);
+    d1 = kblock_sum(d1, lds);
+    d2 = kblock_sum(d2, lds);
+    if (threadIdx.x == 0) { s->part[0][blockIdx.x] = d0; s->part[1][blockIdx.x] = d1; s->part[2][blockIdx.x] = d2; }
+}
+
+__global__ __launch_bounds__(kBlock) void k_kfinish(KScalars *s, int stage, int nblocks)
+{
+    __shared__ double lds[kBlock / 64];
+    double t[3];
+    for (int k = 0; k < 3; ++k) {
+        double d = 0.0;
+        for (int i = threadIdx.x; i < nblocks; i += kBlock) d += s->part[k][i];
+        t[k] = kblock_sum(d, lds);
+    }
+    if (threadIdx.x != 0) return;
+    if (stage == 1) {                    // rho1 = c1.v1, alpha1 = c1.b
+        s->rho1 = t[0];
+        s->alpha1 = t[1];
+        s->f1 = t[0] > 0.0 ? t[1] / t[0] : 0.0;
+        s->f2 = 0.0;
+    } else {                             // gamma = c2.v1, beta = c2.v2, alpha2 = c2.r1
+        s->gamma = t[0];
+        s->beta = t[1];
+        s->alpha2 = t[2];
+        const double rho2 = s->rho1 > 0.0 ? t[1] - t[0] * t[0] / s->rho1 : 0.0;
+        if (rho2 > 0.0 && s->rho1 > 0.0) {
+            s->f1 = s->alpha1 / s->rho1 - t[0] * t[2] / (s->rho1 * rho2);
+            s->f2 = t[2] / rho2;
+        }                                 // else keep the one-step answer
+    }
+}
+
+// r1 = b - f1 v1
+__global__ __launch_bounds__(kBlock) void k_kresid(const double *__restrict__ b,
+                                                  const double *__restrict__ v1, int n,
+                                                  const KScalars *s, double *__restrict__ r1)
+{
+    const double f1 = s->f1;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+        r1[i] = b[i] - f1 * v1[i];
+}
+
+// x = f1 c1 + f2 c2
+__global__ __launch_bounds__(kBlock) void k_kcombine(const double *__restrict__ c1,
+                                                    const double *__restrict__ c2, int n,
+                                                    const KScalars *s, double *__restrict__ x)
+{
+    const double f1 = s->f1, f2 = s->f2;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+        x[i] = f1 * c1[i] + f2 * c2[i];
+}
+
+}  // namespace
+
+size_t amg_workspace_bytes(int rows, int cols)
+{
+    const size_t n = static_cast<size_t>(rows) * cols;
+    // level 0: <= 9n entries (12 B each) + ~60 B/node of vectors and maps; the
+    // hierarchy shrinks geometrically (x ~3.5 in total); sort scratch: two key and
+    // two value buffers of 9n entries (8 B each) + hipCUB temporaries
+    size_t bytes = static_cast<size_t>(4.5 * (9.0 * n * 12 + 96.0 * n));
+    bytes += 4 * 9 * n * 8 + 3 * 9 * n * 8;
+    bytes += static_cast<size_t>(kMaxDense) * kMaxDense * 8 * 3 + (64u << 20);
+    return bytes;
+}
+
+#define AMG_TAKE(ptr, type, count)                                                    \
+    do {                                                                              \
+        ptr = static_cast<type *>(bump.take(sizeof(type) * static_cast<size_t>(count))); \
+        if (!ptr) return set_error(SSRS_ERR_INVALID, "amg: workspace exhausted (%s)", #ptr); \
+    } while (0)
+
+int amg_setup(AmgHierarchy &h, const double *cond, const uint8_t *fixed, int rows, int cols,
+              void *workspace, size_t workspace_bytes, hipStream_t st)
+{
+    h.levels.clear();
+    h.dense_inv = nullptr;
+    Bump bump{static_cast<char *>(workspace), workspace_bytes, 0};
+    const int n0 = rows * cols;
+
+    // ---- level 0
+    AmgLevel L{};
+    L.n = n0;
+    AMG_TAKE(L.rowptr, int, n0 + 1);
+    int *cnt;
+    AMG_TAKE(cnt, int, n0 + 1);
+    hipLaunchKernelGGL(k_l0_count, dim3(grid_for(n0)), dim3(kBlock), 0, st, fixed, rows, cols, cnt);
+    SSRS_HIP_CHECK(hipMemsetAsync(cnt + n0, 0, sizeof(int), st));
+    {
+        size_t tb = 0;
+        SSRS_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, cnt, L.rowptr, n0 + 1, st));
+        void *tmp = bump.take(tb);
+        if (!tmp) return set_error(SSRS_ERR_INVALID, "amg: workspace exhausted (scan)");
+        SSRS_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, tb, cnt, L.rowptr, n0 + 1, st));
+    }
+    SSRS_HIP_CHECK(hipMemcpyAsync(&L.nnz, L.rowptr + n0, sizeof(int), hipMemcpyDeviceToHost, st));
+    SSRS_HIP_CHECK(hipStreamSynchronize(st));
+    AMG_TAKE(L.col, int, L.nnz);
+    AMG_TAKE(L.val, double, L.nnz);
+    hipLaunchKernelGGL(k_l0_fill, dim3(grid_for(n0)), dim3(kBlock), 0, st, cond, fixed, rows, cols,
+                       L.rowptr, L.col, L.val);
+    SSRS_HIP_CHECK(hipGetLastError());
+
+    // sort scratch sized for level 0 (the largest)
+    unsigned long long *keys_a, *keys_b;
+    double *vals_a, *vals_b;
+    AMG_TAKE(keys_a, unsigned long long, L.nnz);
+    AMG_TAKE(keys_b, unsigned long long, L.nnz);
+    AMG_TAKE(vals_a, double, L.nnz);
+    AMG_TAKE(vals_b, double, L.nnz);
+    int *d_count;
+    AMG_TAKE(d_count, int, 4);
+    size_t sort_tb = 0, red_tb = 0, scan_tb = 0;
+    SSRS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tb, keys_a, keys_b, vals_a, vals_b,
+                                                      L.nnz, 0, 64, st));
+    SSRS_HIP_CHECK(hipcub::DeviceReduce::ReduceByKey(nullptr, red_tb, keys_b, keys_a, vals_b, vals_a,
+                                                     d_count, hipcub::Sum(), L.nnz, st));
+    SSRS_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tb, cnt, cnt, n0 + 1, st));
+    size_t cub_tb = sort_tb > red_tb ? sort_tb : red_tb;
+    cub_tb = cub_tb > scan_tb ? cub_tb : scan_tb;
+    void *cub_tmp = bump.take(cub_tb);
+    if (!cub_tmp) return set_error(SSRS_ERR_INVALID, "amg: workspace exhausted (cub)");
+
+    for (int lev = 0;; ++lev) {
+        const int n = L.n;
+        AMG_TAKE(L.dinv, double, n);
+        AMG_TAKE(L.x, double, n);
+        AMG_TAKE(L.xt, double, n);
+        AMG_TAKE(L.b, double, n);
+        AMG_TAKE(L.r, double, n);
+        if (lev >= 1 && lev <= h.kdepth) {
+            AMG_TAKE(L.kb, double, n);
+            AMG_TAKE(L.c1, double, n);
+            AMG_TAKE(L.v1, double, n);
+            AMG_TAKE(L.v2, double, n);
+            void *ks;
+            AMG_TAKE(ks, char, sizeof(KScalars));
+            L.kscal = ks;
+        }
+        hipLaunchKernelGGL(k_dinv, dim3(grid_for(n)), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, n, L.dinv);
+        L.agg = nullptr;
+        L.members = nullptr;
+        L.nc = 0;
+        if ((n <= kMaxDense && lev > 0) || lev >= 48) { h.levels.push_back(L); break; }
+
+        // ---- pairwise aggregation
+        int *match, *prop, *joined, *flag, *cid;
+        unsigned long long *third;
+        AMG_TAKE(L.agg, int, n);
+        AMG_TAKE(match, int, n);
+        AMG_TAKE(prop, int, n);
+        AMG_TAKE(joined, int, n);
+        AMG_TAKE(flag, int, n + 1);
+        AMG_TAKE(cid, int, n + 1);
+        AMG_TAKE(third, unsigned long long, n);
+        SSRS_HIP_CHECK(hipMemsetAsync(match, 0xFF, sizeof(int) * n, st));
+        SSRS_HIP_CHECK(hipMemsetAsync(third, 0, sizeof(unsigned long long) * n, st));
+        for (int round = 0; round < kMatchRounds; ++round) {
+            hipLaunchKernelGGL(k_propose, dim3(grid_for(n)), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, n,
+                               match, prop, round < h.strong_rounds ? kTheta : 0.0);
+            hipLaunchKernelGGL(k_accept, dim3(grid_for(n)), dim3(kBlock), 0, st, n, prop, match);
+        }
+        hipLaunchKernelGGL(k_apply_join, dim3(grid_for(n)), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, n, match, third);
+        hipLaunchKernelGGL(k_leader_flags, dim3(grid_for(n)), dim3(kBlock), 0, st, L.rowptr, n, match, third, joined, flag);
+        hipLaunchKernelGGL(k_resolve_join, dim3(grid_for(n)), dim3(kBlock), 0, st, n, match, third, joined, flag);
+        SSRS_HIP_CHECK(hipMemsetAsync(flag + n, 0, sizeof(int), st));
+        {
+            size_t tb = cub_tb;
+            SSRS_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, tb, flag, cid, n + 1, st));
+        }
+        int nc = 0;
+        SSRS_HIP_CHECK(hipMemcpyAsync(&nc, cid + n, sizeof(int), hipMemcpyDeviceToHost, st));
+        SSRS_HIP_CHECK(hipStreamSynchronize(st));
+        if (nc == 0 || nc > 0.93 * n) {           // nothing (left) to coarsen
+            L.agg = nullptr;
+            h.levels.push_back(L);
+            break;
+        }
+        AMG_TAKE(L.members, int, 3 * static_cast<size_t>(nc));
+        hipLaunchKernelGGL(k_assign_agg, dim3(grid_for(n)), dim3(kBlock), 0, st, L.rowptr, n, match, joined, flag,
+                           cid, L.agg, L.members);
+        hipLaunchKernelGGL(k_third_member, dim3(grid_for(n)), dim3(kBlock), 0, st, n, joined, L.agg, L.members);
+        L.nc = nc;
+
+        // ---- Galerkin coarse matrix: sort (I,J) keys, sum duplicates
+        hipLaunchKernelGGL(k_galerkin_keys, dim3(grid_for(n)), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, n, L.agg,
+                           keys_a, vals_a);
+        {
+            size_t tb = cub_tb;
+            SSRS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(cub_tmp, tb, keys_a, keys_b, vals_a, vals_b, L.nnz, 0, 64, st));
+            tb = cub_tb;
+            SSRS_HIP_CHECK(hipcub::DeviceReduce::ReduceByKey(cub_tmp, tb, keys_b, keys_a, vals_b, vals_a, d_count,
+                                                             hipcub::Sum(), L.nnz, st));
+        }
+        int nuniq = 0;
+        SSRS_HIP_CHECK(hipMemcpyAsync(&nuniq, d_count, sizeof(int), hipMemcpyDeviceToHost, st));
+        unsigned long long last_key = 0;
+        SSRS_HIP_CHECK(hipStreamSynchronize(st));
+        SSRS_HIP_CHECK(hipMemcpyAsync(&last_key, keys_a + (nuniq - 1), sizeof(last_key), hipMemcpyDeviceToHost, st));
+        SSRS_HIP_CHECK(hipStreamSynchronize(st));
+        if (last_key == ~0ull) --nuniq;            // the parked bucket
+
+        AmgLevel C{};
+        C.n = nc;
+        C.nnz = nuniq;
+        AMG_TAKE(C.rowptr, int, nc + 1);
+        AMG_TAKE(C.col, int, nuniq);
+        AMG_TAKE(C.val, double, nuniq);
+        hipLaunchKernelGGL(k_unpack_coarse, dim3(grid_for(nuniq)), dim3(kBlock), 0, st, keys_a, nuniq, nc, C.rowptr, C.col);
+        SSRS_HIP_CHECK(hipMemcpyAsync(C.val, vals_a, sizeof(double) * nuniq, hipMemcpyDeviceToDevice, st));
+        SSRS_HIP_CHECK(hipGetLastError());
+        h.levels.push_back(L);
+        L = C;
+    }
+    if (h.levels.empty()) return set_error(SSRS_ERR_INVALID, "amg: empty hierarchy");
+
+    // ---- dense inverse of the coarsest level when it is small enough
+    AmgLevel &B = h.levels.back();
+    if (B.n <= kMaxDense) {
+        const int n = B.n;
+        double *aug, *colk;
+        AMG_TAKE(aug, double, static_cast<size_t>(n) * 2 * n);
+        AMG_TAKE(colk, double, n);
+        AMG_TAKE(h.dense_inv, double, static_cast<size_t>(n) * n);
+        hipLaunchKernelGGL(k_dense_fill, dim3(grid_for(static_cast<size_t>(n) * 2 * n)), dim3(kBlock), 0, st, B.rowptr, B.col, B.val, n, aug);
+        hipLaunchKernelGGL(k_dense_scatter, dim3(grid_for(n)), dim3(kBlock), 0, st, B.rowptr, B.col, B.val, n, aug);
+        for (int k = 0; k < n; ++k) {
+            hipLaunchKernelGGL(k_gj_save, dim3(grid_for(n)), dim3(kBlock), 0, st, aug, n, k, colk);
+            hipLaunchKernelGGL(k_gj_elim, dim3(grid_for(static_cast<size_t>(n) * 2 * n)), dim3(kBlock), 0, st, aug, n, k, colk);
+        }
+        hipLaunchKernelGGL(k_gj_finish, dim3(grid_for(static_cast<size_t>(n) * n)), dim3(kBlock), 0, st, aug, n, h.dense_inv);
+        SSRS_HIP_CHECK(hipGetLastError());
+    }
+    SSRS_HIP_CHECK(hipStreamSynchronize(st));
+    h.workspace_used = bump.off;
+    return SSRS_OK;
+}
+
+static void solve_level(AmgHierarchy &h, size_t lev, hipStream_t st);
+
+// One multigrid step at `lev`: rhs L.b -> L.x (smooth, coarse solve, smooth)
+static void cycle(AmgHierarchy &h, size_t lev, hipStream_t st)
+{
+    AmgLevel &L = h.levels[lev];
+    const int n = L.n, g = grid_for(n);
+    if (lev + 1 == h.levels.size()) {
+        if (h.dense_inv) {
+            hipLaunchKernelGGL(k_dense_apply, dim3(g), dim3(kBlock), 0, st, h.dense_inv, L.b, n, L.x);
+        } else {                                   // stalled coarsening: relax
+            hipLaunchKernelGGL(k_jacobi_first, dim3(g), dim3(kBlock), 0, st, L.dinv, L.b, n, L.x);
+            for (int s = 0; s < 20; ++s) {
+                hipLaunchKernelGGL(k_jacobi, dim3(g), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.dinv, L.b, L.x, n, L.xt);
+                hipLaunchKernelGGL(k_jacobi, dim3(g), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.dinv, L.b, L.xt, n, L.x);
+            }
+        }
+        return;
+    }
+    // pre-smoothing: 2*sweeps Jacobi sweeps from x = 0
+    hipLaunchKernelGGL(k_jacobi_first, dim3(g), dim3(kBlock), 0, st, L.dinv, L.b, n, L.xt);
+    hipLaunchKernelGGL(k_jacobi, dim3(g), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.dinv, L.b, L.xt, n, L.x);
+    for (int s = 1; s < h.sweeps; ++s) {
+        hipLaunchKernelGGL(k_jacobi, dim3(g), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.dinv, L.b, L.x, n, L.xt);
+        hipLaunchKernelGGL(k_jacobi, dim3(g), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.dinv, L.b, L.xt, n, L.x);
+    }
+    hipLaunchKernelGGL(k_residual, dim3(g), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.b, L.x, n, L.r);
+    AmgLevel &C = h.levels[lev + 1];
+    hipLaunchKernelGGL(k_restrict, dim3(grid_for(C.n)), dim3(kBlock), 0, st, L.members, L.r, C.n, C.b);
+    solve_level(h, lev + 1, st);
+    hipLaunchKernelGGL(k_prolong_add, dim3(g), dim3(kBlock), 0, st, L.agg, C.x, n, L.x);
+    // post-smoothing
+    for (int s = 0; s < h.sweeps; ++s) {
+        hipLaunchKernelGGL(k_jacobi, dim3(g), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.dinv, L.b, L.x, n, L.xt);
+        hipLaunchKernelGGL(k_jacobi, dim3(g), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.dinv, L.b, L.xt, n, L.x);
+    }
+}
+
+// Approximate solve of level `lev` (rhs L.b -> L.x): on the first `kdepth`
+// coarse levels two FCG steps preconditioned by cycle() (K-cycle), below that a
+// plain V-cycle, on the last level the dense inverse.
+static void solve_level(AmgHierarchy &h, size_t lev, hipStream_t st)
+{
+    AmgLevel &L = h.levels[lev];
+    if (lev + 1 == h.levels.size() || static_cast<int>(lev) > h.kdepth || !L.kscal) {
+        cycle(h, lev, st);
+        return;
+    }
+    const int n = L.n, g = grid_for(n);
+    int gb = g > 256 ? 256 : g;
+    KScalars *ks = static_cast<KScalars *>(L.kscal);
+    hipLaunchKernelGGL(k_copy, dim3(g), dim3(256), 0, st, L.b, L.kb, static_cast<size_t>(n));
+    cycle(h, lev, st);                                                                    // c1 = B b
+    hipLaunchKernelGGL(k_copy, dim3(g), dim3(256), 0, st, L.x, L.c1, static_cast<size_t>(n));
+    hipLaunchKernelGGL(k_spmv, dim3(g), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.c1, n, L.v1);
+    hipLaunchKernelGGL(k_dots, dim3(gb), dim3(kBlock), 0, st, L.c1, L.v1, L.c1, L.kb, nullptr, nullptr, n, ks);
+    hipLaunchKernelGGL(k_kfinish, dim3(1), dim3(kBlock), 0, st, ks, 1, gb);
+    hipLaunchKernelGGL(k_kresid, dim3(g), dim3(kBlock), 0, st, L.kb, L.v1, n, ks, L.b);   // r1 -> rhs
+    cycle(h, lev, st);                                                                    // c2 = B r1 (in L.x)
+    hipLaunchKernelGGL(k_spmv, dim3(g), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.x, n, L.v2);
+    hipLaunchKernelGGL(k_dots, dim3(gb), dim3(kBlock), 0, st, L.x, L.v1, L.x, L.v2, L.x, L.b, n, ks);
+    hipLaunchKernelGGL(k_kfinish, dim3(1), dim3(kBlock), 0, st, ks, 2, gb);
+    hipLaunchKernelGGL(k_kcombine, dim3(g), dim3(kBlock), 0, st, L.c1, L.x, n, ks, L.xt);
+    hipLaunchKernelGGL(k_copy, dim3(g), dim3(256), 0, st, L.xt, L.x, static_cast<size_t>(n));
+}
+
+void amg_apply(AmgHierarchy &h, const double *rhs, double *out, hipStream_t st)
+{
+    AmgLevel &L = h.levels[0];
+    hipLaunchKernelGGL(k_copy, dim3(grid_for(L.n)), dim3(256), 0, st, rhs, L.b, static_cast<size_t>(L.n));
+    cycle(h, 0, st);
+    hipLaunchKernelGGL(k_copy, dim3(grid_for(L.n)), dim3(256), 0, st, L.x, out, static_cast<size_t>(L.n));
+}
+
+}  // namespace ssrs

@@ -7,7 +7,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
-SOURCES = ['capi.hip', 'raster.hip', 'tracks.hip', 'presence.hip', 'potential.hip', 'thermals.hip']
+SOURCES = ['capi.hip', 'raster.hip', 'tracks.hip', 'presence.hip', 'potential.hip', 'thermals.hip', 'amg.hip']
 LIB = os.path.join(PKG, 'libssrs_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
          '-fno-fast-math', '-fgpu-rdc=0' if False else '-Wall', '-Wno-unused-function']
@@ -20,7 +20,7 @@ def _newest(paths):
 def build(force=False, verbose=False):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     srcs = [os.path.join(HERE, s) for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
-    deps = srcs + [os.path.join(HERE, 'common.h'),
+    deps = srcs + [os.path.join(HERE, 'amg.h'), os.path.join(HERE, 'common.h'),
                    os.path.join(os.path.dirname(PKG), 'include', 'ssrs_hip.h')]
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest(deps):
         return LIB

@@ -19,6 +19,7 @@
 // ssrs_amd/potential.py) as a mask + value raster.
 #include <cmath>
 
+#include "amg.h"
 #include "common.h"
 
 namespace ssrs {
@@ -38,6 +39,10 @@ struct StencilArgs {
     const double *cond;
     const uint8_t *fixed;     // 1 = Dirichlet
     int rows, cols;
+    int unnormalised;         // 1: rows of D - C (pairs with the AMG of D - C);
+                              // 0: rows of I - G (= Jacobi-scaled, plain Krylov)
+    int quirk;                // 1: the reference's east-edge weights (exact operator);
+                              // 0: natural weights (symmetric operator, PCG phase)
 };
 
 __device__ __forceinline__ double apply_row(const StencilArgs &a, const double *__restrict__ x,
@@ -47,7 +52,7 @@ __device__ __forceinline__ double apply_row(const StencilArgs &a, const double *
     const size_t i = static_cast<size_t>(r) * C + c;
     const double ci = a.cond[i];
     double wsum = 0.0, acc = 0.0;
-    const bool east_quirk = (c == C - 1) && r > 0 && r < R - 1;
+    const bool east_quirk = a.quirk && (c == C - 1) && r > 0 && r < R - 1;
     // neighbour order is irrelevant for the mathematics; the sum order below is
     // fixed (W, NW, N, NE, E, SE, S, SW) so runs are reproducible
 #pragma unroll
@@ -64,7 +69,7 @@ __device__ __forceinline__ double apply_row(const StencilArgs &a, const double *
         wsum += w;
         acc += w * x[j];
     }
-    return x[i] - acc / wsum;
+    return a.unnormalised ? wsum * x[i] - acc : x[i] - acc / wsum;
 }
 
 constexpr int kRedBlocks = 1024;
@@ -85,7 +90,7 @@ __device__ __forceinline__ double block_sum(double v, double *lds)
 
 // scalars live in device memory so that no iteration waits on the host
 struct Scalars {
-    double rho, rho_old, alpha, omega, rhat_v, ts, tt, rnorm2, bnorm2;
+    double rho, rho_old, alpha, omega, rhat_v, ts, tt, rnorm2, bnorm2, pq, beta;
     double part[6][kRedBlocks];
 };
 
@@ -120,8 +125,9 @@ __global__ __launch_bounds__(kBlock) void k_form_s(const double *__restrict__ r,
 }
 
 // t = A s_vec ; partials (t, s) and (t, t)
-__global__ __launch_bounds__(kBlock) void k_apply_dot2(StencilArgs a, const double *__restrict__ sv,
-                                                      double *__restrict__ t, Scalars *s)
+__global__ __launch_bounds__(kBlock) void k_apply_dot2(StencilArgs a, const double *__restrict__ in,
+                                                      double *__restrict__ t,
+                                                      const double *__restrict__ sv, Scalars *s)
 {
     __shared__ double lds[kBlock / 64];
     const size_t n = static_cast<size_t>(a.rows) * a.cols;
@@ -129,7 +135,7 @@ __global__ __launch_bounds__(kBlock) void k_apply_dot2(StencilArgs a, const doub
     for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
          i += static_cast<size_t>(gridDim.x) * kBlock) {
         double y = 0.0;
-        if (!a.fixed[i]) y = apply_row(a, sv, static_cast<int>(i / a.cols), static_cast<int>(i % a.cols));
+        if (!a.fixed[i]) y = apply_row(a, in, static_cast<int>(i / a.cols), static_cast<int>(i % a.cols));
         t[i] = y;
         d1 += y * sv[i];
         d2 += y * y;
@@ -141,7 +147,8 @@ __global__ __launch_bounds__(kBlock) void k_apply_dot2(StencilArgs a, const doub
 
 // x += alpha p + omega s ; r = s - omega t ; partials (rhat, r), (r, r)
 __global__ __launch_bounds__(kBlock) void k_update_xr(double *__restrict__ x, double *__restrict__ r,
-                                                     const double *__restrict__ p,
+                                                     const double *__restrict__ p,   // M p
+                                                     const double *__restrict__ sh,  // M s
                                                      const double *__restrict__ sv,
                                                      const double *__restrict__ t,
                                                      const double *__restrict__ rhat, size_t n,
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(kBlock) void k_update_xr(double *__restrict__ x, do
     double d1 = 0.0, d2 = 0.0;
     for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
          i += static_cast<size_t>(gridDim.x) * kBlock) {
-        x[i] = x[i] + alpha * p[i] + omega * sv[i];
+        x[i] = x[i] + alpha * p[i] + omega * sh[i];
         const double rn = sv[i] - omega * t[i];
         r[i] = rn;
         d1 += rhat[i] * rn;
@@ -177,7 +184,7 @@ __global__ __launch_bounds__(kBlock) void k_update_p(double *__restrict__ p,
 }
 
 // single-block scalar updates between the vector kernels (deterministic sums)
-enum { FIN_ALPHA = 0, FIN_OMEGA = 1, FIN_RHO = 2, FIN_INIT = 3, FIN_BNORM = 4 };
+enum { FIN_ALPHA = 0, FIN_OMEGA = 1, FIN_RHO = 2, FIN_INIT = 3, FIN_BNORM = 4, FIN_CG_RHO = 5, FIN_CG_RR = 6, FIN_CG_ALPHA = 7 };
 __global__ __launch_bounds__(kBlock) void k_finish(Scalars *s, int what, int nblocks)
 {
     __shared__ double lds[kBlock / 64];
@@ -197,6 +204,16 @@ __global__ __launch_bounds__(kBlock) void k_finish(Scalars *s, int what, int nbl
         const double rho = total(3);
         const double rr = total(4);
         if (threadIdx.x == 0) { s->rho_old = s->rho; s->rho = rho; s->rnorm2 = rr; }
+    } else if (what == FIN_CG_RHO) {         // flexible CG: beta = -(z, q_prev) / (p_prev, q_prev)
+        const double zq = total(3);
+        if (threadIdx.x == 0) s->beta = s->pq != 0.0 ? -zq / s->pq : 0.0;
+    } else if (what == FIN_CG_ALPHA) {       // alpha = (p, r) / (p, q)
+        const double pq = total(0);
+        const double pr = total(1);
+        if (threadIdx.x == 0) { s->pq = pq; s->alpha = pq != 0.0 ? pr / pq : 0.0; }
+    } else if (what == FIN_CG_RR) {
+        const double rr = total(4);
+        if (threadIdx.x == 0) s->rnorm2 = rr;
     } else if (what == FIN_BNORM) {          // |b|^2: residual of the zero field
         const double rr = total(4);
         if (threadIdx.x == 0) s->bnorm2 = rr;
@@ -207,6 +224,69 @@ __global__ __launch_bounds__(kBlock) void k_finish(Scalars *s, int what, int nbl
             s->rnorm2 = rr;
         }
     }
+}
+
+// ---- preconditioned CG on the symmetric operator (phase 1 of the AMG solve)
+__global__ __launch_bounds__(kBlock) void k_cg_dot_rz(const double *__restrict__ r,
+                                                     const double *__restrict__ z, size_t n,
+                                                     Scalars *s)
+{
+    __shared__ double lds[kBlock / 64];
+    double d = 0.0;
+    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * kBlock)
+        d += r[i] * z[i];
+    d = block_sum(d, lds);
+    if (threadIdx.x == 0) s->part[3][blockIdx.x] = d;
+}
+
+__global__ __launch_bounds__(kBlock) void k_cg_p(double *__restrict__ p,
+                                                const double *__restrict__ z, size_t n,
+                                                Scalars *s, int first)
+{
+    const double beta = first ? 0.0 : s->beta;
+    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * kBlock)
+        p[i] = z[i] + beta * p[i];
+}
+
+// q = A p ; partials (p, q) and (p, r)
+__global__ __launch_bounds__(kBlock) void k_cg_apply(StencilArgs a, const double *__restrict__ p,
+                                                    double *__restrict__ q,
+                                                    const double *__restrict__ r, Scalars *s)
+{
+    __shared__ double lds[kBlock / 64];
+    const size_t n = static_cast<size_t>(a.rows) * a.cols;
+    double d0 = 0.0, d1 = 0.0;
+    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * kBlock) {
+        double y = 0.0;
+        if (!a.fixed[i]) y = apply_row(a, p, static_cast<int>(i / a.cols), static_cast<int>(i % a.cols));
+        q[i] = y;
+        d0 += p[i] * y;
+        d1 += p[i] * r[i];
+    }
+    d0 = block_sum(d0, lds);
+    d1 = block_sum(d1, lds);
+    if (threadIdx.x == 0) { s->part[0][blockIdx.x] = d0; s->part[1][blockIdx.x] = d1; }
+}
+
+__global__ __launch_bounds__(kBlock) void k_cg_xr(double *__restrict__ x, double *__restrict__ r,
+                                                 const double *__restrict__ p,
+                                                 const double *__restrict__ q, size_t n, Scalars *s)
+{
+    __shared__ double lds[kBlock / 64];
+    const double alpha = s->alpha;
+    double d = 0.0;
+    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * kBlock) {
+        x[i] = x[i] + alpha * p[i];
+        const double rn = r[i] - alpha * q[i];
+        r[i] = rn;
+        d += rn * rn;
+    }
+    d = block_sum(d, lds);
+    if (threadIdx.x == 0) s->part[4][blockIdx.x] = d;
 }
 
 // set-up: x0 = Dirichlet values on fixed cells / initial guess elsewhere;
@@ -259,20 +339,21 @@ extern "C" size_t ssrs_potential_workspace_bytes(int rows, int cols)
 {
     if (rows <= 0 || cols <= 0) return 0;
     const size_t n = static_cast<size_t>(rows) * cols;
-    return (sizeof(Scalars) + 255) / 256 * 256 + 8 * vec_bytes(n);
+    return (sizeof(Scalars) + 255) / 256 * 256 + 10 * vec_bytes(n) + amg_workspace_bytes(rows, cols) + 256;
 }
 
 typedef struct SsrsSolveStatsInternal {
     int32_t iterations, converged;
     double residual;
     float kernel_ms;
+    int32_t amg_levels, amg_coarsest;
 } SsrsSolveStatsInternal;
 
 extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *fixed_mask,
                                     const double *fixed_values, const double *initial_guess,
                                     float *potential, int rows, int cols, double rel_tol,
-                                    int max_iterations, void *workspace, size_t workspace_bytes,
-                                    void *stats_out, void *stream)
+                                    int max_iterations, int flags, void *workspace,
+                                    size_t workspace_bytes, void *stats_out, void *stream)
 {
     SSRS_REQUIRE(conductivity && fixed_mask && fixed_values && potential && workspace,
                  "ssrs_potential_solve: NULL pointer");
@@ -287,11 +368,24 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
     char *base = static_cast<char *>(workspace);
     Scalars *sc = reinterpret_cast<Scalars *>(base);
     base += (sizeof(Scalars) + 255) / 256 * 256;
-    double *vec[8];
-    for (int i = 0; i < 8; ++i) vec[i] = reinterpret_cast<double *>(base + i * vec_bytes(n));
+    double *vec[10];
+    for (int i = 0; i < 10; ++i) vec[i] = reinterpret_cast<double *>(base + i * vec_bytes(n));
     double *x = vec[0], *r = vec[1], *rhat = vec[2], *p = vec[3], *v = vec[4], *sv = vec[5], *t = vec[6];
-    double *xbest = vec[7];
-    StencilArgs a{conductivity, fixed_mask, rows, cols};
+    double *xbest = vec[7], *phat = vec[8], *shat = vec[9];
+    // right-preconditioned BiCGStab: M = one AMG V-cycle of the symmetric operator
+    const bool use_amg = (flags & SSRS_SOLVE_NO_AMG) == 0;
+    AmgHierarchy amg;
+    amg.sweeps = 1 + ((flags >> 4) & 7);
+    amg.kdepth = (flags & SSRS_SOLVE_K_CYCLE) ? 3 : 0;
+    amg.strong_rounds = ((flags >> 8) & 15) ? ((flags >> 8) & 15) : 4;
+    if (use_amg) {
+        char *amg_base = base + 10 * vec_bytes(n);
+        amg_base = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(amg_base) + 255) / 256 * 256);
+        const size_t amg_bytes = static_cast<size_t>(static_cast<char *>(workspace) + workspace_bytes - amg_base);
+        const int rc = amg_setup(amg, conductivity, fixed_mask, rows, cols, amg_base, amg_bytes, as_stream(stream));
+        if (rc != SSRS_OK) return rc;
+    }
+    StencilArgs a{conductivity, fixed_mask, rows, cols, use_amg ? 1 : 0, 1};
     int nb = static_cast<int>((n + kBlock - 1) / kBlock);
     if (nb > kRedBlocks) nb = kRedBlocks;
     hipEvent_t e0, e1;
@@ -311,20 +405,62 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, st, sc, FIN_INIT, nb);
     SSRS_HIP_CHECK(hipGetLastError());
     double host[2] = {0.0, 0.0};
+    int cg_iterations = 0;
+    if (use_amg) {
+        // ---- phase 1: PCG on the symmetric operator (natural weights).  One
+        // V-cycle + one operator application per iteration; it delivers the
+        // solution up to the east-edge quirk, which phase 2 (BiCGStab on the
+        // exact operator, started from here) removes in a few iterations.
+        StencilArgs as = a;
+        as.quirk = 0;
+        hipLaunchKernelGGL(k_setup, dim3(nb), dim3(kBlock), 0, st, as, x, r, rhat, p, v, sc);
+        hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, st, sc, FIN_INIT, nb);
+        double cg_best = 1e300;
+        int stalled = 0;
+        while (cg_iterations < max_iterations) {
+            for (int j = 0; j < 5; ++j, ++cg_iterations) {
+                // flexible CG(1): the K-cycle preconditioner is slightly non-linear,
+                // so p is A-orthogonalised explicitly against the previous direction
+                amg_apply(amg, r, phat, st);                                        // z = M r
+                hipLaunchKernelGGL(k_cg_dot_rz, dim3(nb), dim3(kBlock), 0, st, phat, v, n, sc);      // (z, q_prev)
+                hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, st, sc, FIN_CG_RHO, nb);
+                hipLaunchKernelGGL(k_cg_p, dim3(nb), dim3(kBlock), 0, st, p, phat, n, sc, cg_iterations == 0 ? 1 : 0);
+                hipLaunchKernelGGL(k_cg_apply, dim3(nb), dim3(kBlock), 0, st, as, p, v, r, sc);     // q = A p
+                hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, st, sc, FIN_CG_ALPHA, nb);
+                hipLaunchKernelGGL(k_cg_xr, dim3(nb), dim3(kBlock), 0, st, x, r, p, v, n, sc);
+                hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, st, sc, FIN_CG_RR, nb);
+            }
+            SSRS_HIP_CHECK(hipGetLastError());
+            SSRS_HIP_CHECK(hipMemcpyAsync(host, &sc->rnorm2, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+            SSRS_HIP_CHECK(hipStreamSynchronize(st));
+            if (!(host[0] == host[0])) break;
+            const double now = host[1] > 0.0 ? std::sqrt(host[0] / host[1]) : 0.0;
+            if (now <= rel_tol) break;
+            if (now < 0.5 * cg_best) { cg_best = now; stalled = 0; }
+            else if (++stalled >= 40) break;           // 200 iterations without halving
+        }
+        // hand over to BiCGStab on the exact operator
+        hipLaunchKernelGGL(k_setup, dim3(nb), dim3(kBlock), 0, st, a, x, r, rhat, p, v, sc);
+        hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, st, sc, FIN_INIT, nb);
+        SSRS_HIP_CHECK(hipGetLastError());
+    }
     int it = 0, converged = 0, restarts = 0;
-    const int check_every = 25, max_restarts = 50;
+    const int check_every = use_amg ? 5 : 25, max_restarts = 50;
     double rel = 1.0, best = 1e300;
     bool fresh = true;                     // p == r (no k_update_p on the first pass)
     while (it < max_iterations) {
         for (int j = 0; j < check_every && it < max_iterations; ++j, ++it) {
             if (!fresh) hipLaunchKernelGGL(k_update_p, dim3(nb), dim3(kBlock), 0, st, p, r, v, n, sc);
             fresh = false;
-            hipLaunchKernelGGL(k_apply_dot1, dim3(nb), dim3(kBlock), 0, st, a, p, v, rhat, sc);
+            const double *ph = p, *sh = sv;
+            if (use_amg) { amg_apply(amg, p, phat, st); ph = phat; }
+            hipLaunchKernelGGL(k_apply_dot1, dim3(nb), dim3(kBlock), 0, st, a, ph, v, rhat, sc);
             hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, st, sc, FIN_ALPHA, nb);
             hipLaunchKernelGGL(k_form_s, dim3(nb), dim3(kBlock), 0, st, r, v, sv, n, sc);
-            hipLaunchKernelGGL(k_apply_dot2, dim3(nb), dim3(kBlock), 0, st, a, sv, t, sc);
+            if (use_amg) { amg_apply(amg, sv, shat, st); sh = shat; }
+            hipLaunchKernelGGL(k_apply_dot2, dim3(nb), dim3(kBlock), 0, st, a, sh, t, sv, sc);
             hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, st, sc, FIN_OMEGA, nb);
-            hipLaunchKernelGGL(k_update_xr, dim3(nb), dim3(kBlock), 0, st, x, r, p, sv, t, rhat, n, sc);
+            hipLaunchKernelGGL(k_update_xr, dim3(nb), dim3(kBlock), 0, st, x, r, ph, sh, sv, t, rhat, n, sc);
             hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, st, sc, FIN_RHO, nb);
         }
         SSRS_HIP_CHECK(hipGetLastError());
@@ -359,10 +495,12 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
     (void)hipEventDestroy(e1);
     if (stats_out) {
         auto *so = static_cast<SsrsSolveStatsInternal *>(stats_out);
-        so->iterations = it;
+        so->iterations = it + cg_iterations;
         so->converged = converged;
         so->residual = rel;
         so->kernel_ms = ms;
+        so->amg_levels = use_amg ? static_cast<int32_t>(amg.levels.size()) : 0;
+        so->amg_coarsest = use_amg ? amg.levels.back().n : 0;
     }
     return SSRS_OK;
 }

@@ -364,6 +364,8 @@ struct StepArgs {
     int fast;                    // guarded division-free decision (see choose_move)
     int steps;                   // S
     int coherent;                // tracks carry a release step in aux
+    uint32_t *visits;            // [steps][visit_stride] visited cell per slot (K3 binning), or NULL
+    long long visit_stride;
 };
 
 __global__ __launch_bounds__(kBlock) void k_tracks_init(
@@ -434,6 +436,7 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
     uint32_t pend_a = 0, pend_b = 0;   // words (2,3) of the current Philox block
     bool have_pending = false;
     uint32_t moved = 0;
+    int last_it = -1;
 
     const int lane_id = threadIdx.x & 63;
 
@@ -540,14 +543,28 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
         // a fetch queued behind the atomic would pay the atomic's latency too.
         // (er, ec) is always a cell of the raster, also for finished lanes.
         fetch_entry();
-        // ---- presence histogram (K3).  Issued by every lane on every iteration
-        // (idle lanes add 0 to their own, valid, cell): with exactly one VMEM
-        // op behind the four fetches the compiler can wait for the fetches with
-        // vmcnt(1) and leave the atomic in flight; a conditional atomic forces
-        // vmcnt(0) and puts the atomic's round trip on every step's critical path.
-        if (a.hist)
+        // ---- presence histogram (K3).  Every lane issues exactly one VMEM op
+        // behind the four fetches on every iteration, so the compiler waits for
+        // the fetches with vmcnt(1) (a conditional op would force vmcnt(0) and put
+        // its round trip on every step's critical path).
+        //  * binning mode: the visited cell goes to visits[it][slot] with a
+        //    coalesced store; k_bin_visits turns each step's row of the buffer
+        //    into histogram counts through an LDS window (device-scope atomics are
+        //    memory-side on MI355X: ~2e10 64-B requests/s chip-wide, which made
+        //    per-step atomics the stepper's limit: 10.6 ms vs 6.3 ms without)
+        //  * fallback: one atomic per lane (idle lanes add 0 to their own cell)
+        if (a.visits) {
+            a.visits[static_cast<long long>(it) * a.visit_stride + i] =
+                stepped ? static_cast<uint32_t>(row) * a.cols + col : 0xFFFFFFFFu;
+        } else if (a.hist) {
             atomicAdd(&a.hist[static_cast<size_t>(row) * a.cols + col], stepped ? 1u : 0u);
+        }
+        last_it = it;
     }
+    // a wave that ran out of live lanes early still owns its slots of the buffer
+    if (a.visits)
+        for (int it = last_it + 1; it < a.steps; ++it)
+            a.visits[static_cast<long long>(it) * a.visit_stride + i] = 0xFFFFFFFFu;
 
     // ---- wave-level compaction of the survivors into the next launch's list
     const unsigned long long live = __ballot(active);
@@ -573,6 +590,60 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
     if (lane == 0 && m) atomicAdd(&ctl->steps, m);
 }
 
+// K3 binning: one block per step of the launch.  The coherent schedule keeps the
+// whole batch on a front a few raster rows deep, so one step's visits fall into
+// a window of a few rows: counted with LDS atomics, flushed with contiguous
+// (full-rate) global atomics of the non-zero cells; stragglers outside the
+// window fall back to single global atomics.
+constexpr int kBinThreads = 1024;
+constexpr int kBinCells = 30720;          // 120 KB of LDS
+__global__ __launch_bounds__(kBinThreads) void k_bin_visits(const uint32_t *__restrict__ visits,
+                                                           long long stride,
+                                                           const TrackCtl *__restrict__ ctl, int slot,
+                                                           uint32_t *__restrict__ hist, int rows,
+                                                           int cols)
+{
+    __shared__ uint32_t bins[kBinCells];
+    __shared__ uint32_t s_first;
+    const uint32_t nlive = ctl->count[slot];
+    const uint32_t nslots = (nlive + 63u) & ~63u;      // whole waves wrote their slots
+    const uint32_t *v = visits + static_cast<long long>(blockIdx.x) * stride;
+    const uint32_t ncell = static_cast<uint32_t>(rows) * cols;
+    const int wrows = kBinCells / cols < 1 ? 0 : (kBinCells / cols > rows ? rows : kBinCells / cols);
+    if (threadIdx.x == 0) s_first = 0xFFFFFFFFu;
+    for (int k = threadIdx.x; k < wrows * cols; k += kBinThreads) bins[k] = 0;
+    __syncthreads();
+    // window origin: the smallest visited cell's row
+    uint32_t mn = 0xFFFFFFFFu;
+    for (uint32_t j = threadIdx.x; j < nslots; j += kBinThreads) {
+        const uint32_t c = v[j];
+        mn = c < mn ? c : mn;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = __shfl_down(mn, off);
+        mn = o < mn ? o : mn;
+    }
+    if ((threadIdx.x & 63) == 0 && mn != 0xFFFFFFFFu) atomicMin(&s_first, mn);
+    __syncthreads();
+    const uint32_t first = s_first;
+    if (first == 0xFFFFFFFFu) return;                  // nobody moved in this step
+    const uint32_t base = (first / cols) * cols;       // first cell of the window
+    const uint32_t wcells = static_cast<uint32_t>(wrows) * cols;
+    for (uint32_t j = threadIdx.x; j < nslots; j += kBinThreads) {
+        const uint32_t c = v[j];
+        if (c >= ncell) continue;                      // idle slot
+        const uint32_t off = c - base;
+        if (off < wcells) atomicAdd(&bins[off], 1u);
+        else atomicAdd(&hist[c], 1u);
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < wcells && base + k < ncell; k += kBinThreads) {
+        const uint32_t n = bins[k];
+        if (n) atomicAdd(&hist[base + k], n);
+    }
+}
+
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Workspace {
@@ -582,7 +653,11 @@ struct Workspace {
     unsigned long long *keys[2];
     void *sort_temp;
     size_t sort_temp_bytes;
+    uint32_t *visits[2];         // double-buffered: binning of launch L overlaps stepping of L+1
+    long long visit_stride;
 };
+
+constexpr int kVisitSteps = 256;   // binning mode covers launches of up to this many steps
 
 static size_t sort_temp_size(int64_t n)
 {
@@ -612,6 +687,11 @@ static size_t workspace_layout(int64_t n, char *base, Workspace *ws)
     const size_t temp = n > 0 ? sort_temp_size(n) : 0;
     if (ws) { ws->sort_temp = base + off; ws->sort_temp_bytes = temp; }
     off = align_up(off + temp, 256);
+    const long long stride = (n + 63) / 64 * 64;
+    for (int i = 0; i < 2; ++i) {
+        if (ws) { ws->visits[i] = reinterpret_cast<uint32_t *>(base + off); ws->visit_stride = stride; }
+        off = align_up(off + sizeof(uint32_t) * static_cast<size_t>(stride) * kVisitSteps, 256);
+    }
     return off;
 }
 
@@ -622,6 +702,14 @@ static uint32_t *pinned_counts()
     if (!buf && hipHostMalloc(reinterpret_cast<void **>(&buf), 64 * sizeof(uint32_t)) != hipSuccess)
         buf = nullptr;
     return buf;
+}
+
+// side stream for the histogram binning kernels, one per host thread
+static hipStream_t side_stream()
+{
+    static thread_local hipStream_t s = nullptr;
+    if (!s && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;
+    return s;
 }
 
 }  // namespace ssrs
@@ -767,6 +855,25 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
     a.state = ws.state; a.ctl = ws.ctl; a.steps = S;
     a.fast = ((p->flags & SSRS_TRACKS_EXACT_ONLY) == 0 && p->scaling_parameter == 1.0) ? 1 : 0;
     a.coherent = coherent ? 1 : 0;
+    // binning needs the coherent front (a step's visits fall into a few rows)
+    // The binning kernel runs on the SAME stream, after its stepper launch.  Running it
+    // on a side stream to overlap the next launch was measured and rejected: its
+    // 1024-thread / 120-KB-LDS blocks crowd the latency-bound stepper waves (stepper
+    // 6.4 -> 10.2 ms, binning 1.4 -> 3.5 ms; profiles/r01_notes.md).
+    constexpr bool kOverlapBinning = false;
+    hipStream_t st2 = kOverlapBinning ? side_stream() : st;
+    const bool binning = hist != nullptr && coherent && S <= kVisitSteps &&
+                         (!kOverlapBinning || st2 != nullptr) &&
+                         (p->flags & SSRS_TRACKS_NO_BINNING) == 0 && p->cols <= kBinCells;
+    a.visits = nullptr;
+    a.visit_stride = ws.visit_stride;
+    hipEvent_t ev_step[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    bool done_valid[2] = {false, false};
+    if (binning)
+        for (int i = 0; i < 2; ++i) {
+            SSRS_HIP_CHECK(hipEventCreateWithFlags(&ev_step[i], hipEventDisableTiming));
+            SSRS_HIP_CHECK(hipEventCreateWithFlags(&ev_done[i], hipEventDisableTiming));
+        }
 
     // Launch loop.  Launches are queued kBatch deep; the live count of a batch
     // is copied back asynchronously and examined while the next batch runs, so
@@ -774,7 +881,7 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
     constexpr int kBatch = 4, kRing = 8;
     hipEvent_t ev_batch[kRing];
     for (int i = 0; i < kRing; ++i) SSRS_HIP_CHECK(hipEventCreate(&ev_batch[i]));
-    std::vector<hipEvent_t> ev_prof;
+    std::vector<hipEvent_t> ev_prof, ev_bin, ev_hist;   // launch starts / ends; binning kernel brackets
     int launch = 0;
     uint32_t upper = static_cast<uint32_t>(ntracks);   // bound on the live count
     int batches = 0, checked = 0;
@@ -788,6 +895,11 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
             a.list_in = (launch == 0 && !coherent) ? nullptr : ws.list[launch & 1];
             a.list_out = ws.list[(launch + 1) & 1];
             const unsigned blocks = (upper + kBlock - 1) / kBlock;
+            const int vb = launch & 1;
+            if (binning) {
+                a.visits = ws.visits[vb];
+                if (kOverlapBinning && done_valid[vb]) (void)hipStreamWaitEvent(st, ev_done[vb], 0);   // buffer free again
+            }
             if (profile) {
                 hipEvent_t e;
                 if (hipEventCreate(&e) == hipSuccess) { hipEventRecord(e, st); ev_prof.push_back(e); }
@@ -797,6 +909,31 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
             case MODE_FLUIDFLOW: hipLaunchKernelGGL(k_step_tracks<MODE_FLUIDFLOW>, dim3(blocks), dim3(kBlock), 0, st, a); break;
             case MODE_UPDRAFT: hipLaunchKernelGGL(k_step_tracks<MODE_UPDRAFT>, dim3(blocks), dim3(kBlock), 0, st, a); break;
             default: hipLaunchKernelGGL(k_step_tracks<MODE_PRIOR>, dim3(blocks), dim3(kBlock), 0, st, a); break;
+            }
+            if (profile) {      // end of the stepper launch
+                hipEvent_t e;
+                if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); ev_bin.push_back(e); }
+            }
+            if (binning) {
+                // binning of this launch runs on the side stream, overlapping the next
+                // stepper launch (which writes the other visit buffer)
+                if (kOverlapBinning) {
+                    (void)hipEventRecord(ev_step[vb], st);
+                    (void)hipStreamWaitEvent(st2, ev_step[vb], 0);
+                }
+                hipEvent_t b0 = nullptr, b1 = nullptr;
+                if (profile && hipEventCreate(&b0) == hipSuccess) (void)hipEventRecord(b0, st2);
+                hipLaunchKernelGGL(k_bin_visits, dim3(S), dim3(kBinThreads), 0, st2, ws.visits[vb], ws.visit_stride,
+                                   ws.ctl, launch & 3, hist, p->rows, p->cols);
+                if (profile && b0 && hipEventCreate(&b1) == hipSuccess) {
+                    (void)hipEventRecord(b1, st2);
+                    ev_hist.push_back(b0);
+                    ev_hist.push_back(b1);
+                }
+                if (kOverlapBinning) {
+                    (void)hipEventRecord(ev_done[vb], st2);
+                    done_valid[vb] = true;
+                }
             }
             if (hipGetLastError() != hipSuccess) { rc = set_error(SSRS_ERR_HIP, "stepper launch failed"); break; }
         }
@@ -820,11 +957,14 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
             upper = c;   // the live count only shrinks; a stale bound is safe
         }
     }
+    if (binning)
+        for (int i = 0; i < 2; ++i)
+            if (done_valid[i]) (void)hipStreamWaitEvent(st, ev_done[i], 0);    // histogram complete on `stream`
     if (profile) {
         hipEvent_t e;
-        if (hipEventCreate(&e) == hipSuccess) { hipEventRecord(e, st); ev_prof.push_back(e); }
+        if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); ev_prof.push_back(e); }
     }
-    hipEventRecord(ev_last, st);
+    (void)hipEventRecord(ev_last, st);
     // fetch step total + error flag
     TrackCtl host_ctl = {};
     if (rc == SSRS_OK) {
@@ -842,13 +982,24 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, ev_first, ev_last) == hipSuccess) stats->wall_ms = ms;
         if (profile) {
-            float sum = 0.f;
-            for (size_t i = 0; i + 1 < ev_prof.size(); ++i)
-                if (hipEventElapsedTime(&ms, ev_prof[i], ev_prof[i + 1]) == hipSuccess) sum += ms;
+            // stepper launch i: ev_prof[i] -> ev_bin[i]; binning kernels (side stream,
+            // overlapped with the next launch): ev_hist[2j] -> ev_hist[2j+1]
+            float sum = 0.f, hsum = 0.f;
+            for (size_t i = 0; i < ev_bin.size() && i < ev_prof.size(); ++i)
+                if (hipEventElapsedTime(&ms, ev_prof[i], ev_bin[i]) == hipSuccess) sum += ms;
+            for (size_t i = 0; i + 1 < ev_hist.size(); i += 2)
+                if (hipEventElapsedTime(&ms, ev_hist[i], ev_hist[i + 1]) == hipSuccess) hsum += ms;
             stats->kernel_ms = sum;
+            stats->hist_ms = hsum;
         }
     }
     for (hipEvent_t e : ev_prof) hipEventDestroy(e);
+    for (hipEvent_t e : ev_bin) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ev_hist) (void)hipEventDestroy(e);
+    for (int i = 0; i < 2; ++i) {
+        if (ev_step[i]) (void)hipEventDestroy(ev_step[i]);
+        if (ev_done[i]) (void)hipEventDestroy(ev_done[i]);
+    }
     for (int i = 0; i < kRing; ++i) hipEventDestroy(ev_batch[i]);
     hipEventDestroy(ev_first);
     hipEventDestroy(ev_last);

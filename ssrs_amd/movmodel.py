@@ -75,7 +75,8 @@ def get_directional_probs(theta):
 
 
 def make_track_params(grid_shape, move_dirn, memory_parameter=1, scaling_parameter=1.,
-                      steps_per_launch=0, profile=False, exact_only=False, schedule=True):
+                      steps_per_launch=0, profile=False, exact_only=False, schedule=True,
+                      binning=True):
     rows, cols = int(grid_shape[0]), int(grid_shape[1])
     p = nat.SsrsTrackParams()
     nat.check(nat.lib().ssrs_track_params_init(C.byref(p), rows, cols, int(memory_parameter),
@@ -86,7 +87,8 @@ def make_track_params(grid_shape, move_dirn, memory_parameter=1, scaling_paramet
     p.steps_per_launch = int(steps_per_launch)
     p.flags = (nat.SSRS_TRACKS_PROFILE if profile else 0) | \
         (nat.SSRS_TRACKS_EXACT_ONLY if exact_only else 0) | \
-        (0 if schedule else nat.SSRS_TRACKS_NO_SCHEDULE)
+        (0 if schedule else nat.SSRS_TRACKS_NO_SCHEDULE) | \
+        (0 if binning else nat.SSRS_TRACKS_NO_BINNING)
     return p
 
 
@@ -127,7 +129,7 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
                     scaling_parameter=1., updraft_field=None, potential_field=None, *,
                     seed=0, track_id_base=0, table=None, use_table=None, hist=None,
                     want_hist=True, want_tracks=False, steps_per_launch=0, profile=False,
-                    exact_only=False, schedule=True):
+                    exact_only=False, schedule=True, binning=True):
     """generate_simulated_tracks for a whole batch (movmodel.py:264-318 under
     simulator.py:360-369) + presence histogram (movmodel.py:410-419).
 
@@ -157,7 +159,7 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
         if use_table:
             table = build_transition_table(upd, pot)
     p = make_track_params((rows, cols), move_dirn, memory_parameter, scaling_parameter,
-                          steps_per_launch, profile, exact_only, schedule)
+                          steps_per_launch, profile, exact_only, schedule, binning)
     if hist is None and want_hist:
         hist = torch.zeros((rows, cols), dtype=torch.int32, device=dev)
     lengths = torch.empty(n, dtype=torch.int32, device=dev)
@@ -188,7 +190,8 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
         run(hist, None, None)
     return TrackBatch(lengths, ends, hist, traj, offsets,
                       dict(total_steps=int(stats.total_steps), launches=int(stats.launches),
-                           kernel_ms=float(stats.kernel_ms), wall_ms=float(stats.wall_ms)))
+                           kernel_ms=float(stats.kernel_ms), wall_ms=float(stats.wall_ms),
+                           hist_ms=float(stats.hist_ms)))
 
 
 def generate_simulated_tracks(move_dirn, start_location, grid_shape, memory_parameter=1,

@@ -60,8 +60,8 @@ def dirichlet_rasters(move_dirn, grid_shape):
     return mask, vals
 
 
-def solve_potential(updraft, move_dirn, rel_tol=1e-12, max_iterations=200000,
-                    initial_guess=None, return_stats=False):
+def solve_potential(updraft, move_dirn, rel_tol=1e-12, max_iterations=2000,
+                    initial_guess=None, return_stats=False, use_amg=True, extra_sweeps=0, cycle='V', strong_rounds=0):
     """MovModel(...).solve_sparse_linear_system equivalent -> f32 (rows, cols).
 
     `updraft` is the conductivity raster (usable updraft, f64); numpy in ->
@@ -79,7 +79,9 @@ def solve_potential(updraft, move_dirn, rel_tol=1e-12, max_iterations=200000,
     stats = nat.SsrsSolveStats()
     nat.check(nat.lib().ssrs_potential_solve(
         nat.ptr(cond), nat.ptr(mask), nat.ptr(vals), nat.ptr(guess), nat.ptr(out),
-        rows, cols, C.c_double(rel_tol), int(max_iterations), nat.ptr(ws),
+        rows, cols, C.c_double(rel_tol), int(max_iterations),
+        (0 if use_amg else nat.SSRS_SOLVE_NO_AMG) | (int(extra_sweeps) << 4) |
+        (2 if cycle == 'K' else 0) | (int(strong_rounds) << 8), nat.ptr(ws),
         C.c_size_t(nbytes), C.byref(stats), stream_ptr()))
     if not stats.converged:
         import warnings
@@ -88,5 +90,6 @@ def solve_potential(updraft, move_dirn, rel_tol=1e-12, max_iterations=200000,
     res = like_input(out, updraft)
     if return_stats:
         return res, dict(iterations=int(stats.iterations), converged=bool(stats.converged),
-                         residual=float(stats.residual), kernel_ms=float(stats.kernel_ms))
+                         residual=float(stats.residual), kernel_ms=float(stats.kernel_ms),
+                         amg_levels=int(stats.amg_levels), amg_coarsest=int(stats.amg_coarsest))
     return res

@@ -68,38 +68,46 @@ def test_boundary_nodes_vs_golden(golden):
         assert np.array_equal(bn, g[f'bnodes_{tag}']) and np.array_equal(be, g[f'benergy_{tag}'])
 
 
-@pytest.mark.parametrize('dirn', [0., 180., 90., 30.])
+@pytest.mark.parametrize('dirn', [0., 180., -45., 90., 30.])
 def test_potential_vs_reference_spsolve(gpu, golden, dirn):
-    """Matrix-free BiCGStab vs the reference's SuperLU solution (f32 output) on
-    the 48 x 64 golden.  The system is ill-conditioned (zero-updraft cells are
-    linked with 1e-8 conductances, movmodel.py:442-447), so a 1e-12 residual is
-    needed for a 0.1 (1e-4 of the 0..1000 range) agreement."""
-    from ssrs_amd.potential import solve_potential
+    """AMG-preconditioned solve vs the reference's SuperLU solution (f32
+    output) on the 48 x 64 golden, all boundary configurations.  Tolerance:
+    2 f32 ulps of the 0..1000 range (1.3e-4)."""
+    from ssrs_amd.potential import solve_potential, dirichlet_rasters
     g = golden('g5_potential.npz')
-    pot, st = solve_potential(g['updraft'], dirn, rel_tol=1e-12, max_iterations=100000,
-                              return_stats=True)
+    pot, st = solve_potential(g['updraft'], dirn, rel_tol=1e-12, return_stats=True)
     ref = g[f'pot_d{int(dirn % 360)}']
-    assert st['converged'], st
+    assert st['converged'] and st['iterations'] < 200, st
     assert pot.dtype == np.float32 and pot.shape == ref.shape
-    np.testing.assert_allclose(pot, ref, rtol=0, atol=0.1)
-    # Dirichlet cells are reproduced exactly
-    from ssrs_amd.potential import dirichlet_rasters
+    np.testing.assert_allclose(pot, ref, rtol=0, atol=1.3e-4)
     mask, vals = dirichlet_rasters(dirn, ref.shape)
     assert np.array_equal(pot[mask == 1], vals[mask == 1].astype(np.float32))
+    # determinism: the hierarchy uses no float atomics
+    pot2 = solve_potential(g['updraft'], dirn, rel_tol=1e-12)
+    assert np.array_equal(pot, pot2)
 
 
-@pytest.mark.xfail(reason='K5 v1 (unpreconditioned BiCGStab) stalls on high-contrast rasters: '
-                          'floating conductive clusters need a multilevel coarse space '
-                          '(DESIGN.md "K5", planned aggregation AMG)', strict=False)
 def test_potential_c1_vs_golden(gpu, golden):
+    """Config C1 (500 x 600): the reference needs 1.3 s assembly + 10.8 s SuperLU
+    (BASELINE.md); tolerance 1e-3 of the 0..1000 range on the f32 field."""
     from ssrs_amd import layers
     from ssrs_amd.potential import solve_potential
     g = golden('g8_c1.npz')
     upd = layers.get_above_threshold_speed(g['orograph_f32'], 0.75)
-    import warnings
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        pot, st = solve_potential(upd, 0., rel_tol=1e-12, max_iterations=20000,
-                                  return_stats=True)
-    assert st['converged'], st
-    np.testing.assert_allclose(pot, g['potential'], rtol=0, atol=0.1)
+    pot, st = solve_potential(upd, 0., rel_tol=1e-10, return_stats=True)
+    print('C1 potential solve:', st)
+    assert st['converged'] and st['amg_levels'] >= 5, st
+    np.testing.assert_allclose(pot, g['potential'], rtol=0, atol=1e-3)
+
+
+def test_plain_bicgstab_switch_still_works_on_benign_problem(gpu):
+    """A/B switch: without the AMG the solver is the v1 Jacobi-scaled BiCGStab,
+    fine for uniform conductance (exact answer = linear ramp)."""
+    from ssrs_amd.potential import solve_potential
+    cond = np.ones((40, 30))
+    ramp = 1000. * (1 - np.arange(40)[:, None] / 39.) * np.ones((1, 30))
+    for amg in (True, False):
+        pot, st = solve_potential(cond, 0., rel_tol=1e-12, max_iterations=5000,
+                                  return_stats=True, use_amg=amg)
+        assert st['converged'], st
+        np.testing.assert_allclose(pot, ramp, rtol=0, atol=2e-3 if not amg else 2e-4)

@@ -42,7 +42,7 @@ def test_uniform_fluidflow_end_to_end(gpu, tmp_path):
     trk_file = os.path.join(sim.mode_data_dir, 's10d270_d0_t75_fluidflow_r0_tracks.pkl')
     pot = np.load(pot_file)
     assert pot.dtype == np.float32
-    np.testing.assert_allclose(pot, orc.solve_potential(upd, 0.), rtol=0, atol=0.5)
+    np.testing.assert_allclose(pot, orc.solve_potential(upd, 0.), rtol=0, atol=1e-3)
     with open(trk_file, 'rb') as f:
         tracks = pickle.load(f)
     assert len(tracks) == 200 and tracks[0].dtype == np.int16 and tracks[0].shape[1] == 2

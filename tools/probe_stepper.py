@@ -22,6 +22,7 @@ variants = {
     'table nohist nosched': dict(table=table, want_hist=False, schedule=False),
     'direct+hist': dict(use_table=False, want_hist=True),
     'table+hist exact': dict(table=table, want_hist=True, exact_only=True),
+    'table+hist nobin': dict(table=table, want_hist=True, binning=False),
 }
 res_ms = {k: [] for k in variants}
 for rep in range(3):
@@ -32,6 +33,6 @@ for rep in range(3):
             h.zero_()
         out = movmodel.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=30, hist=h,
                                        want_hist=h is not None, profile=True, **kw)
-        res_ms[name].append(out.stats['kernel_ms'])
+        res_ms[name].append(out.stats['kernel_ms'] + out.stats['hist_ms'])
 for name, v in res_ms.items():
     print(f'{name:24s} kernel_ms min {min(v):8.3f} med {sorted(v)[1]:8.3f}  steps {out.stats["total_steps"]}')
