@@ -97,12 +97,20 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with '
                          f'torch.distributed.run --nproc-per-node {args.gpus}')
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
+    # one rank per GPU; SSRS_BENCH_BACKEND=gloo lets several ranks share one GPU to
+    # rehearse the N > 1 code path on a single-GPU box (RCCL refuses duplicate devices)
+    backend = os.environ.get('SSRS_BENCH_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world,
+                                    device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from ssrs_amd import layers, movmodel, _native
     from ssrs_amd.distributed import shard_range, reduce_histogram
@@ -198,7 +206,8 @@ def main():
     K = args.steps
     lengths = last.lengths.cpu().numpy()
     steps_per_track = float(lengths.mean() - 1)
-    assert int(hist.sum().item()) == (int(lengths.sum()) if world == 1 else int(hist.sum().item()))
+    # checksum of checksums: every trajectory point was counted exactly once
+    assert int(hist.sum().item()) == total_steps_all // K + n_total, 'histogram checksum failed'
     kernel_s = acc['step_kernel_ms'] / 1e3
     achieved = acc['steps'] * STEP_BYTES / kernel_s / 1e9 if kernel_s > 0 else 0.0
     raster_s = acc['raster_ms'] / 1e3 / K
@@ -219,7 +228,8 @@ def main():
                          f'threshold 0.75, direction 0, seed 30 (BASELINE.json configs[1])'),
             'tracks_total': n_total,
             'parallelism': f'track-sharded x{world}, replicated rasters'
-                           + (', RCCL histogram reduce' if world > 1 else ''),
+                           + (f', {"RCCL" if backend == "nccl" else backend} histogram reduce'
+                              if world > 1 else ''),
             'stepper_path': 'direct 3x3 gathers' if args.direct else 'transition table',
             'potential': pot_label,
         },

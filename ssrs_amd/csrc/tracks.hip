@@ -248,15 +248,29 @@ __device__ __forceinline__ void window_weights(const double *__restrict__ updraf
 }
 
 // ------------------------------------------------------------ transition table
-// One thread per cell: 9+9 cached reads, one 64-B row of 8 f64 written.
+// One thread per cell: 9+9 cached reads, one 64-B row of 8 f64 written.  Blocks
+// own 64 x 16 cell tiles walked in an XCD-aware order (blocks b and b+8 share an
+// XCD, so each XCD gets one contiguous band of tiles): the rows above and below
+// a tile are then found in the same XCD's L2 instead of being re-fetched from
+// HBM by another XCD (PMC before: 2.7x read over-fetch with row-strip blocks).
+constexpr int kTabW = 64, kTabH = 16;
+__device__ __forceinline__ int xcd_band(int b, int n)
+{
+    const int q = n / 8, r = n % 8, x = b % 8, j = b / 8;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
 __global__ __launch_bounds__(kBlock) void k_transition_table(
     const double *__restrict__ updraft, const float *__restrict__ potential,
-    double *__restrict__ table, int rows, int cols)
+    double *__restrict__ table, int rows, int cols, int tiles_x, int ntiles)
 {
-    const size_t n = static_cast<size_t>(rows) * cols;
-    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
-         i += static_cast<size_t>(gridDim.x) * kBlock) {
-        const int row = static_cast<int>(i / cols), col = static_cast<int>(i - static_cast<size_t>(row) * cols);
+    const int t = xcd_band(blockIdx.x, ntiles);
+    const int r0 = (t / tiles_x) * kTabH, c0 = (t % tiles_x) * kTabW;
+    const int col = c0 + static_cast<int>(threadIdx.x % kTabW);
+    if (col >= cols) return;
+    for (int row = r0 + static_cast<int>(threadIdx.x / kTabW); row < r0 + kTabH && row < rows;
+         row += kBlock / kTabW) {
+        const size_t i = static_cast<size_t>(row) * cols + col;
         double w[9];
         bool interior = row > 0 && col > 0 && row < rows - 1 && col < cols - 1;
         if (interior) {
@@ -745,11 +759,9 @@ extern "C" int ssrs_transition_table_build(const double *updraft, const float *p
     SSRS_REQUIRE(rows >= 3 && cols >= 3, "ssrs_transition_table_build: need rows, cols >= 3");
     SSRS_REQUIRE((reinterpret_cast<uintptr_t>(table) & 63u) == 0,
                  "ssrs_transition_table_build: table must be 64-byte aligned");
-    const size_t n = static_cast<size_t>(rows) * cols;
-    size_t blocks = (n + kBlock - 1) / kBlock;
-    if (blocks > static_cast<size_t>(kMaxStreamBlocks) * 4) blocks = kMaxStreamBlocks * 4;
-    hipLaunchKernelGGL(k_transition_table, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0,
-                       as_stream(stream), updraft, potential, table, rows, cols);
+    const int tx = (cols + kTabW - 1) / kTabW, ty = (rows + kTabH - 1) / kTabH, nt = tx * ty;
+    hipLaunchKernelGGL(k_transition_table, dim3(static_cast<unsigned>(nt)), dim3(kBlock), 0,
+                       as_stream(stream), updraft, potential, table, rows, cols, tx, nt);
     SSRS_HIP_CHECK(hipGetLastError());
     return SSRS_OK;
 }

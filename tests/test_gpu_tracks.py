@@ -248,3 +248,72 @@ def test_sharding_invariance_and_hist_checksum(gpu):
     again = movmodel.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=30,
                                      use_table=True)
     assert torch.equal(again.hist, whole.hist) and torch.equal(again.ends, whole.ends)
+
+
+def test_concurrent_streams_from_host_threads(gpu):
+    """Seasonal-mode shape (BASELINE configs[4]: one snapshot per stream): four
+    host threads, each with its own HIP stream and its own updraft/potential,
+    run ssrs_tracks_simulate concurrently; every result equals its serial run."""
+    import threading
+    from ssrs_amd import movmodel
+    rows, cols = 200, 220
+    cases = []
+    rng = np.random.default_rng(21)
+    for s in range(4):
+        upd, pot = _random_field_case(rows, cols, 300 + s)
+        starts = np.stack([rng.integers(2, 20, 1500), rng.integers(0, cols, 1500)], 1)
+        cases.append((torch.from_numpy(upd).cuda(), torch.from_numpy(pot).cuda(),
+                      torch.from_numpy(starts.astype(np.int32)).cuda(), 1000 + s))
+    serial = [movmodel.simulate_tracks(0., st, (rows, cols), 1, 1., u, p, seed=sd)
+              for u, p, st, sd in cases]
+    torch.cuda.synchronize()
+    results = [None] * 4
+    errors = []
+
+    def work(i):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                u, p, st, sd = cases[i]
+                results[i] = movmodel.simulate_tracks(0., st, (rows, cols), 1, 1., u, p, seed=sd)
+            stream.synchronize()
+        except Exception as exc:          # pragma: no cover
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for a, b in zip(results, serial):
+        assert torch.equal(a.lengths, b.lengths) and torch.equal(a.ends, b.ends)
+        assert torch.equal(a.hist, b.hist)
+
+
+def test_c2_scale_properties(gpu):
+    """BASELINE configs[1] at full size (5000 x 6000, 100k tracks): properties
+    that need no oracle -- histogram checksum, determinism across data paths and
+    schedules, and a 2000-track sample bit-exact against the C oracle."""
+    from ssrs_amd import movmodel, layers
+    from ssrs_amd.synthetic import synthetic_dem, ramp_potential
+    from oracle import c_oracle
+    rows, cols, res = 5000, 6000, 10.
+    dem = torch.from_numpy(synthetic_dem((rows, cols), res)).cuda()
+    _, upd = layers.updraft_from_dem(dem, res, 10., 270., threshold=0.75)
+    pot = torch.from_numpy(ramp_potential((rows, cols))).cuda()
+    np.random.seed(30)
+    r, c = movmodel.get_starting_indices(100000, (5, 55, 1, 2), 'random', (60., 50.), res)
+    starts = np.stack([r, c], 1).astype(np.int32)
+    a = movmodel.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=30, use_table=True)
+    assert int(a.hist.sum()) == int(a.lengths.sum())
+    assert int(a.lengths.min()) >= 4800 and int(a.lengths.max()) <= 4902
+    b = movmodel.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=30, use_table=True,
+                                 schedule=False, binning=False, exact_only=True)
+    assert torch.equal(a.lengths, b.lengths) and torch.equal(a.ends, b.ends)
+    assert torch.equal(a.hist, b.hist)
+    m = 2000
+    ref = c_oracle.simulate_tracks(0., starts[:m], (rows, cols), 1, 1., upd.cpu().numpy(),
+                                   pot.cpu().numpy(), seed=30, want_traj=False)
+    assert np.array_equal(a.lengths[:m].cpu().numpy(), ref['lengths'])
+    assert np.array_equal(a.ends[:m].cpu().numpy(), ref['ends'])
