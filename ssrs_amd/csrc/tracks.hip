@@ -702,10 +702,10 @@ static size_t workspace_layout(int64_t n, char *base, Workspace *ws)
     if (ws) { ws->sort_temp = base + off; ws->sort_temp_bytes = temp; }
     off = align_up(off + temp, 256);
     const long long stride = (n + 63) / 64 * 64;
-    for (int i = 0; i < 2; ++i) {
-        if (ws) { ws->visits[i] = reinterpret_cast<uint32_t *>(base + off); ws->visit_stride = stride; }
-        off = align_up(off + sizeof(uint32_t) * static_cast<size_t>(stride) * kVisitSteps, 256);
-    }
+    // one buffer: binning runs on the launch stream right after its stepper launch
+    // (a second buffer would only be needed to overlap it with the next launch)
+    if (ws) { ws->visits[0] = ws->visits[1] = reinterpret_cast<uint32_t *>(base + off); ws->visit_stride = stride; }
+    off = align_up(off + sizeof(uint32_t) * static_cast<size_t>(stride) * kVisitSteps, 256);
     return off;
 }
 
@@ -872,7 +872,7 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
     // on a side stream to overlap the next launch was measured and rejected: its
     // 1024-thread / 120-KB-LDS blocks crowd the latency-bound stepper waves (stepper
     // 6.4 -> 10.2 ms, binning 1.4 -> 3.5 ms; profiles/r01_notes.md).
-    constexpr bool kOverlapBinning = false;
+    constexpr bool kOverlapBinning = false;   // needs two visit buffers (workspace_layout) if enabled
     hipStream_t st2 = kOverlapBinning ? side_stream() : st;
     const bool binning = hist != nullptr && coherent && S <= kVisitSteps &&
                          (!kOverlapBinning || st2 != nullptr) &&

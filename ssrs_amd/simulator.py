@@ -346,33 +346,66 @@ class Simulator(Config):
         starts = np.stack([starting_rows, starting_cols], 1).astype(np.int32)
         use_table = {'auto': None, 'table': True, 'direct': False}[self.stepper_path]
         self.last_stats = {}
-        for case_id in self.case_ids:
-            updrafts = self.load_updrafts(case_id, apply_threshold=True)
-            for real_id, updraft in enumerate(updrafts):
-                if self.sim_seed > 0:
-                    np.random.seed(self.sim_seed + real_id)
-                id_str = self._get_id_string(case_id, real_id)
-                if self.movement_model == 'fluidflow':
-                    potential = self.get_directional_potential(updraft, case_id, real_id)
-                    fields = (updraft, potential)
-                elif self.movement_model == 'drw':
-                    fields = (None, None)
-                else:
-                    raise ValueError(f'unknown movement_model {self.movement_model!r}')
-                print(f'{id_str}: Simulating {self.track_count} tracks..', end="", flush=True)
-                start_time = time.time()
+        # (case, realisation) items are independent: like the reference's loop
+        # they are prepared in order on this thread (file cache, reseeding), then
+        # stepped concurrently, one HIP stream per worker thread (seasonal mode
+        # has many small batches that cannot fill the GPU one at a time).
+        def prepare():
+            for case_id in self.case_ids:
+                updrafts = self.load_updrafts(case_id, apply_threshold=True)
+                for real_id, updraft in enumerate(updrafts):
+                    if self.sim_seed > 0:
+                        np.random.seed(self.sim_seed + real_id)
+                    if self.movement_model == 'fluidflow':
+                        potential = self.get_directional_potential(updraft, case_id, real_id)
+                        fields = (updraft, potential)
+                    elif self.movement_model == 'drw':
+                        fields = (None, None)
+                    else:
+                        raise ValueError(f'unknown movement_model {self.movement_model!r}')
+                    yield (case_id, real_id, fields, self._stream_seed(real_id))
+
+        def run(item):
+            case_id, real_id, fields, seed = item
+            id_str = self._get_id_string(case_id, real_id)
+            start_time = time.time()
+            with torch.cuda.stream(torch.cuda.Stream()):
                 batch = movmodel.simulate_tracks(
                     self.track_direction, starts, self.gridsize, self.track_dirn_restrict,
-                    self.track_stochastic_nu, fields[0], fields[1],
-                    seed=self._stream_seed(real_id), use_table=use_table,
-                    want_tracks=bool(self.save_tracks), steps_per_launch=self.steps_per_launch)
-                print(f'took {_elapsed(start_time)}', flush=True)
-                self._presence_counts[(case_id, real_id)] = batch.hist
-                self.last_stats[(case_id, real_id)] = batch.stats
-                if self.save_tracks:
-                    fname = self._get_tracks_fname(case_id, real_id, self.mode_data_dir)
-                    with open(f'{fname}.pkl', "wb") as fobj:
-                        pickle.dump(batch.tracks(), fobj)
+                    self.track_stochastic_nu, fields[0], fields[1], seed=seed,
+                    use_table=use_table, want_tracks=bool(self.save_tracks),
+                    steps_per_launch=self.steps_per_launch)
+                tracks = batch.tracks() if self.save_tracks else None
+                torch.cuda.current_stream().synchronize()
+            print(f'{id_str}: Simulating {self.track_count} tracks..took {_elapsed(start_time)}',
+                  flush=True)
+            if self.save_tracks:
+                fname = self._get_tracks_fname(case_id, real_id, self.mode_data_dir)
+                with open(f'{fname}.pkl', "wb") as fobj:
+                    pickle.dump(tracks, fobj)
+            return (case_id, real_id), batch
+
+        nitems = len(self.case_ids) * (1 + int(self.thermals_realization_count))
+        workers = max(1, min(nitems, int(self.max_cores), 8))
+
+        def collect(results):
+            for key, batch in results:
+                self._presence_counts[key] = batch.hist
+                self.last_stats[key] = batch.stats
+
+        if workers == 1:
+            collect(run(it) for it in prepare())
+        else:
+            # bounded pipeline: at most `workers` prepared items (host rasters) alive
+            from concurrent.futures import ThreadPoolExecutor, wait, FIRST_COMPLETED
+            with ThreadPoolExecutor(workers) as pool:
+                pending = set()
+                for it in prepare():
+                    pending.add(pool.submit(run, it))
+                    if len(pending) >= workers:
+                        done, pending = wait(pending, return_when=FIRST_COMPLETED)
+                        collect(f.result() for f in done)
+                collect(f.result() for f in pending)
 
     # ------------------------------------------------------------- presence
     def _counts_for(self, case_id, real_id):
