@@ -150,7 +150,11 @@ __device__ __forceinline__ uint32_t edge_hash(uint32_t a, uint32_t b)
 
 __device__ __forceinline__ unsigned long long edge_priority(double w, uint32_t i, uint32_t j)
 {   // positive doubles order like their bit patterns; the low 20 mantissa bits
-    // are replaced by a symmetric hash so that equal weights tie-break randomly
+    // are replaced by a symmetric hash so that equal weights tie-break randomly.
+    // Measured alternatives (tools/probe_solver_media.py, profiles/r01_notes.md):
+    // hash-only among strong couplings and octave buckets + hash coarsen smooth
+    // 1e-10..1 gradients (where heaviest-first handshaking only matches chain
+    // tops) but are 2-7x slower on the real SSRS rasters, so heaviest-first stays.
     unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(w));
     return (b & ~0xFFFFFull) | (edge_hash(i, j) & 0xFFFFFu);
 }
@@ -249,8 +253,10 @@ __global__ __launch_bounds__(kBlock) void k_resolve_join(int n, const int *__res
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         if (match[i] >= 0 && i < match[i] && third[i] != 0ull) {
             const int applicant = static_cast<int>(third[i] & 0xFFFFFFFFull);
-            joined_to[applicant] = i;
-            flag[applicant] = 0;
+            if (applicant >= 0 && applicant < n) {     // always true; guards the index
+                joined_to[applicant] = i;
+                flag[applicant] = 0;
+            }
         }
     }
 }
