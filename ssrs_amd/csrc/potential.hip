@@ -18,6 +18,7 @@
 // Dirichlet cells come from the host (MovModel.get_boundary_nodes restated in
 // ssrs_amd/potential.py) as a mask + value raster.
 #include <cmath>
+#include <cstdlib>
 
 #include "amg.h"
 #include "common.h"
@@ -406,6 +407,7 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
     SSRS_HIP_CHECK(hipGetLastError());
     double host[2] = {0.0, 0.0};
     int cg_iterations = 0;
+    const bool progress = std::getenv("SSRS_PROGRESS") != nullptr;   // long solves: heartbeat on stderr
     if (use_amg) {
         // ---- phase 1: PCG on the symmetric operator (natural weights).  One
         // V-cycle + one operator application per iteration; it delivers the
@@ -435,6 +437,8 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
             SSRS_HIP_CHECK(hipStreamSynchronize(st));
             if (!(host[0] == host[0])) break;
             const double now = host[1] > 0.0 ? std::sqrt(host[0] / host[1]) : 0.0;
+            if (progress && cg_iterations % 250 == 0)
+                fprintf(stderr, "[ssrs_potential_solve] PCG it %d |r|/|b| %.3e\n", cg_iterations, now);
             if (now <= rel_tol) break;
             if (now < 0.5 * cg_best) { cg_best = now; stalled = 0; }
             else if (++stalled >= 40) break;           // 200 iterations without halving

@@ -441,10 +441,13 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
     if (active) s = a.state[t];
     active = active && s.k >= 0;
     int row = s.pos & 0xFFFF, col = (s.pos >> 16) & 0xFFFF;
-    long long k = s.k;
+    int k = s.k;                                   // max_moves < 2^31 (checked by the host)
+    const int max_k = static_cast<int>(a.max_k);
     uint32_t dirs = s.dirs, run = s.aux & 0x1FFu;
-    const long long release = a.coherent ? static_cast<long long>(s.aux >> 9) : 0;
-    const long long g0 = static_cast<long long>(a.launch) * a.steps;   // global step of it = 0
+    // release step relative to this launch's first global step (both < 2^31)
+    const long long rel64 = (a.coherent ? static_cast<long long>(s.aux >> 9) : 0) -
+                            static_cast<long long>(a.launch) * a.steps;
+    const int release = rel64 > 0x7fffffffLL ? 0x7fffffff : (rel64 < 0 ? 0 : static_cast<int>(rel64));
     const unsigned long long track = a.track_base + static_cast<unsigned long long>(t);
     const long long toff = (a.traj && active) ? a.traj_off[t] : 0;
     uint32_t pend_a = 0, pend_b = 0;   // words (2,3) of the current Philox block
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
     bool done = false;
     int er = row, ec = col;
     auto loop_head = [&]() {
-        done = !(k < a.max_k);
+        done = !(k < max_k);
         er = row;
         ec = col;
         if (!done) {
@@ -487,7 +490,7 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
     for (int it = 0; it < a.steps; ++it) {
         if (!__any(active)) break;
         bool stepped = false;
-        if (active && g0 + it >= release) {
+        if (active && it >= release) {
             if (done) {
                 if (a.lengths) a.lengths[t] = static_cast<int32_t>(k + 1);
                 if (a.end_rc)
@@ -508,7 +511,9 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
                 const double u = words_to_uniform(wa, wb);
                 // ---- direction memory (movmodel.py:307-309)
                 uint32_t mask = kAllButCentre;
-                if (a.memory == 0) {
+                if (a.memory == 1) {                 // the reference default: last move only
+                    mask = restriction_of(dirs & 0xFu);
+                } else if (a.memory == 0) {
                     mask = run;
                 } else {
                     uint32_t d = dirs;
@@ -541,7 +546,7 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
                 row = er + idx / 3 - 1;
                 col = ec + idx % 3 - 1;
                 dirs = (dirs << 4) | static_cast<uint32_t>(idx);
-                run &= restriction_of(static_cast<uint32_t>(idx));
+                if (a.memory == 0) run &= restriction_of(static_cast<uint32_t>(idx));
                 ++k;
                 ++moved;
                 stepped = true;
@@ -592,7 +597,7 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
         a.list_out[base + rank] = t;
         TrackState o;
         o.pos = row | (col << 16);
-        o.k = static_cast<int32_t>(k);
+        o.k = k;
         o.dirs = dirs;
         o.aux = run | (s.aux & ~0x1FFu);
         a.state[t] = o;
@@ -676,7 +681,7 @@ constexpr int kVisitSteps = 256;   // binning mode covers launches of up to this
 static size_t sort_temp_size(int64_t n)
 {
     size_t bytes = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, static_cast<const unsigned long long *>(nullptr),
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, static_cast<const unsigned long long *>(nullptr),
                                        static_cast<unsigned long long *>(nullptr),
                                        static_cast<const int32_t *>(nullptr),
                                        static_cast<int32_t *>(nullptr), static_cast<int>(n), 0, 40);
@@ -914,7 +919,7 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
             }
             if (profile) {
                 hipEvent_t e;
-                if (hipEventCreate(&e) == hipSuccess) { hipEventRecord(e, st); ev_prof.push_back(e); }
+                if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); ev_prof.push_back(e); }
             }
             switch (mode) {
             case MODE_TABLE: hipLaunchKernelGGL(k_step_tracks<MODE_TABLE>, dim3(blocks), dim3(kBlock), 0, st, a); break;
@@ -986,7 +991,7 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
         else
             memcpy(&host_ctl, &host_counts[32], sizeof(TrackCtl));
     } else {
-        hipStreamSynchronize(st);
+        (void)hipStreamSynchronize(st);
     }
     if (stats && rc == SSRS_OK) {
         stats->total_steps = static_cast<int64_t>(host_ctl.steps);
@@ -1005,16 +1010,16 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
             stats->hist_ms = hsum;
         }
     }
-    for (hipEvent_t e : ev_prof) hipEventDestroy(e);
+    for (hipEvent_t e : ev_prof) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_bin) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_hist) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) {
         if (ev_step[i]) (void)hipEventDestroy(ev_step[i]);
         if (ev_done[i]) (void)hipEventDestroy(ev_done[i]);
     }
-    for (int i = 0; i < kRing; ++i) hipEventDestroy(ev_batch[i]);
-    hipEventDestroy(ev_first);
-    hipEventDestroy(ev_last);
+    for (int i = 0; i < kRing; ++i) (void)hipEventDestroy(ev_batch[i]);
+    (void)hipEventDestroy(ev_first);
+    (void)hipEventDestroy(ev_last);
     if (rc != SSRS_OK) return rc;
     if (host_ctl.error)
         return set_error(SSRS_ERR_START, "ssrs_tracks_simulate: a start cell lies outside the %d x %d raster",
