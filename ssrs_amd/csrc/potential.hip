@@ -440,8 +440,8 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
             if (progress && cg_iterations % 250 == 0)
                 fprintf(stderr, "[ssrs_potential_solve] PCG it %d |r|/|b| %.3e\n", cg_iterations, now);
             if (now <= rel_tol) break;
-            if (now < 0.5 * cg_best) { cg_best = now; stalled = 0; }
-            else if (++stalled >= 40) break;           // 200 iterations without halving
+            if (now < 0.9 * cg_best) { cg_best = now; stalled = 0; }
+            else if (++stalled >= 100) break;          // 500 iterations without a 10 % gain
         }
         // hand over to BiCGStab on the exact operator
         hipLaunchKernelGGL(k_setup, dim3(nb), dim3(kBlock), 0, st, a, x, r, rhat, p, v, sc);
@@ -452,8 +452,12 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
     const int check_every = use_amg ? 5 : 25, max_restarts = 50;
     double rel = 1.0, best = 1e300;
     bool fresh = true;                     // p == r (no k_update_p on the first pass)
-    while (it < max_iterations) {
-        for (int j = 0; j < check_every && it < max_iterations; ++j, ++it) {
+    // after the PCG phase BiCGStab only has to remove the quirk's defect: it gets
+    // what is left of the iteration budget (at least 50)
+    int bicg_cap = max_iterations;
+    if (use_amg) bicg_cap = max_iterations - cg_iterations > 50 ? max_iterations - cg_iterations : 50;
+    while (it < bicg_cap) {
+        for (int j = 0; j < check_every && it < bicg_cap; ++j, ++it) {
             if (!fresh) hipLaunchKernelGGL(k_update_p, dim3(nb), dim3(kBlock), 0, st, p, r, v, n, sc);
             fresh = false;
             const double *ph = p, *sh = sv;
@@ -472,6 +476,8 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
         SSRS_HIP_CHECK(hipStreamSynchronize(st));
         const bool finite = host[0] == host[0] && host[0] < 1e300;
         const double now = finite && host[1] > 0.0 ? std::sqrt(host[0] / host[1]) : (finite ? 0.0 : 1e300);
+        if (progress && it % 250 == 0)
+            fprintf(stderr, "[ssrs_potential_solve] BiCGStab it %d |r|/|b| %.3e\n", it, now);
         if (finite && now < best) {
             best = now;
             rel = now;

@@ -264,18 +264,50 @@ __global__ __launch_bounds__(kBlock) void k_transition_table(
     const double *__restrict__ updraft, const float *__restrict__ potential,
     double *__restrict__ table, int rows, int cols, int tiles_x, int ntiles)
 {
+    // LDS tiles (+1-cell halo) of the clipped updraft reciprocals and of the
+    // potential: every cell's 1/max(u, 1e-6) is needed by its 9 neighbours, so it
+    // is computed once here instead of 9 times (the harmonic mean of
+    // movmodel.py:260 is 2 / (1/u_c + 1/u_k): identical operands, identical bits).
+    constexpr int LW = kTabW + 2, LH = kTabH + 2;
+    __shared__ double s_inv[LW * LH];
+    __shared__ float s_pot[LW * LH];
     const int t = xcd_band(blockIdx.x, ntiles);
     const int r0 = (t / tiles_x) * kTabH, c0 = (t % tiles_x) * kTabW;
-    const int col = c0 + static_cast<int>(threadIdx.x % kTabW);
+    for (int i = threadIdx.x; i < LW * LH; i += kBlock) {
+        const int lr = i / LW, lc = i - lr * LW;
+        int gr = r0 - 1 + lr, gc = c0 - 1 + lc;
+        gr = gr < 0 ? 0 : (gr >= rows ? rows - 1 : gr);   // clamped cells feed border
+        gc = gc < 0 ? 0 : (gc >= cols ? cols - 1 : gc);   // outputs only (zeroed below)
+        const size_t g = static_cast<size_t>(gr) * cols + gc;
+        const double v = updraft[g];
+        const double w = v != v ? v : (v > 1e-06 ? v : 1e-06);   // clip(min=1e-06), NaN kept
+        s_inv[i] = 1.0 / w;
+        s_pot[i] = potential ? potential[g] : 0.f;
+    }
+    __syncthreads();
+    const int lc = static_cast<int>(threadIdx.x % kTabW) + 1;
+    const int col = c0 + lc - 1;
     if (col >= cols) return;
-    for (int row = r0 + static_cast<int>(threadIdx.x / kTabW); row < r0 + kTabH && row < rows;
-         row += kBlock / kTabW) {
+    for (int lr = static_cast<int>(threadIdx.x / kTabW) + 1; lr <= kTabH; lr += kBlock / kTabW) {
+        const int row = r0 + lr - 1;
+        if (row >= rows) break;
         const size_t i = static_cast<size_t>(row) * cols + col;
         double w[9];
-        bool interior = row > 0 && col > 0 && row < rows - 1 && col < cols - 1;
+        const bool interior = row > 0 && col > 0 && row < rows - 1 && col < cols - 1;
         if (interior) {
-            if (potential) window_weights<true>(updraft, potential, cols, row, col, w);
-            else window_weights<false>(updraft, potential, cols, row, col, w);
+            const double ic = s_inv[lr * LW + lc];
+            const float pc = s_pot[lr * LW + lc];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const int o = (lr + dr_of(j)) * LW + lc + dc_of(j);
+                w[j] = 2.0 / (ic + s_inv[o]);                       // harmonic mean
+                if (potential) {
+                    const float d = pc - s_pot[o];
+                    const float ninv = (j == 4) ? 0.f : ((j & 1) ? 1.f : SSRS_NINV_DIAG);
+                    const float e = d * ninv;                       // stays f32
+                    w[j] = w[j] * static_cast<double>(e);
+                }
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < 9; ++j) w[j] = 0.0;
@@ -309,6 +341,8 @@ struct alignas(16) TrackCtl {
     uint32_t error;              // != 0: some start cell was outside the raster
     uint32_t par_min;            // smallest along-track start coordinate (schedule)
     unsigned long long steps;    // total moves taken
+    unsigned long long strays;   // visits the binning kernel could not place in its LDS window
+    unsigned long long pad;
 };
 
 // Coherent schedule.  Tracks are independent, so the order in which lanes pick
@@ -618,7 +652,7 @@ constexpr int kBinThreads = 1024;
 constexpr int kBinCells = 30720;          // 120 KB of LDS
 __global__ __launch_bounds__(kBinThreads) void k_bin_visits(const uint32_t *__restrict__ visits,
                                                            long long stride,
-                                                           const TrackCtl *__restrict__ ctl, int slot,
+                                                           TrackCtl *__restrict__ ctl, int slot,
                                                            uint32_t *__restrict__ hist, int rows,
                                                            int cols)
 {
@@ -649,13 +683,19 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_visits(const uint32_t *__re
     if (first == 0xFFFFFFFFu) return;                  // nobody moved in this step
     const uint32_t base = (first / cols) * cols;       // first cell of the window
     const uint32_t wcells = static_cast<uint32_t>(wrows) * cols;
+    uint32_t stray = 0;
     for (uint32_t j = threadIdx.x; j < nslots; j += kBinThreads) {
         const uint32_t c = v[j];
         if (c >= ncell) continue;                      // idle slot
         const uint32_t off = c - base;
         if (off < wcells) atomicAdd(&bins[off], 1u);
-        else atomicAdd(&hist[c], 1u);
+        else { atomicAdd(&hist[c], 1u); ++stray; }
     }
+    // stray count -> host: when the batch no longer moves as a front (tracks
+    // trapped or scattered) the host switches back to in-stepper atomics
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) stray += __shfl_down(stray, off);
+    if ((threadIdx.x & 63) == 0 && stray) atomicAdd(&ctl->strays, static_cast<unsigned long long>(stray));
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < wcells && base + k < ncell; k += kBinThreads) {
         const uint32_t n = bins[k];
@@ -718,7 +758,7 @@ static size_t workspace_layout(int64_t n, char *base, Workspace *ws)
 static uint32_t *pinned_counts()
 {
     static thread_local uint32_t *buf = nullptr;
-    if (!buf && hipHostMalloc(reinterpret_cast<void **>(&buf), 64 * sizeof(uint32_t)) != hipSuccess)
+    if (!buf && hipHostMalloc(reinterpret_cast<void **>(&buf), 256 * sizeof(uint32_t)) != hipSuccess)
         buf = nullptr;
     return buf;
 }
@@ -884,6 +924,8 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
                          (p->flags & SSRS_TRACKS_NO_BINNING) == 0 && p->cols <= kBinCells;
     a.visits = nullptr;
     a.visit_stride = ws.visit_stride;
+    bool binning_on = binning && ntracks >= 8192;   // small batches: plain atomics are cheaper
+    unsigned long long seen_steps = 0, seen_strays = 0;
     hipEvent_t ev_step[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     bool done_valid[2] = {false, false};
     if (binning)
@@ -913,7 +955,8 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
             a.list_out = ws.list[(launch + 1) & 1];
             const unsigned blocks = (upper + kBlock - 1) / kBlock;
             const int vb = launch & 1;
-            if (binning) {
+            a.visits = nullptr;
+            if (binning_on) {
                 a.visits = ws.visits[vb];
                 if (kOverlapBinning && done_valid[vb]) (void)hipStreamWaitEvent(st, ev_done[vb], 0);   // buffer free again
             }
@@ -931,7 +974,7 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
                 hipEvent_t e;
                 if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); ev_bin.push_back(e); }
             }
-            if (binning) {
+            if (binning_on) {
                 // binning of this launch runs on the side stream, overlapping the next
                 // stepper launch (which writes the other visit buffer)
                 if (kOverlapBinning) {
@@ -957,7 +1000,10 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
         if (rc != SSRS_OK) break;
         // survivors of this batch = input count of the next launch
         const int slot = batches % kRing;
-        if (hipMemcpyAsync(&host_counts[slot], &ws.ctl->count[launch & 3], sizeof(uint32_t),
+        // ring slot = 8 words: [live count, -, steps (2 words), strays (2 words), -, -]
+        if (hipMemcpyAsync(&host_counts[8 * slot], &ws.ctl->count[launch & 3], sizeof(uint32_t),
+                           hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipMemcpyAsync(&host_counts[8 * slot + 2], &ws.ctl->steps, 2 * sizeof(unsigned long long),
                            hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipEventRecord(ev_batch[slot], st) != hipSuccess) {
             rc = set_error(SSRS_ERR_HIP, "live-count read-back failed");
@@ -968,10 +1014,21 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
         while (checked < batches - 1) {
             const int cs = checked % kRing;
             if (hipEventSynchronize(ev_batch[cs]) != hipSuccess) { rc = set_error(SSRS_ERR_HIP, "event sync failed"); break; }
-            const uint32_t c = host_counts[cs];
+            const uint32_t c = host_counts[8 * cs];
+            unsigned long long tot[2];
+            memcpy(tot, &host_counts[8 * cs + 2], sizeof(tot));
             ++checked;
             if (c == 0) { finished = true; break; }
             upper = c;   // the live count only shrinks; a stale bound is safe
+            // binning pays only while the batch moves as a front: once more than a
+            // quarter of a batch's visits miss the LDS window, later launches go back
+            // to in-stepper atomics
+            if (binning_on) {
+                const unsigned long long dsteps = tot[0] - seen_steps, dstray = tot[1] - seen_strays;
+                if (dsteps > 0 && dstray * 4 > dsteps) binning_on = false;
+            }
+            seen_steps = tot[0];
+            seen_strays = tot[1];
         }
     }
     if (binning)
@@ -985,11 +1042,11 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
     // fetch step total + error flag
     TrackCtl host_ctl = {};
     if (rc == SSRS_OK) {
-        if (hipMemcpyAsync(&host_counts[32], ws.ctl, sizeof(TrackCtl), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        if (hipMemcpyAsync(&host_counts[128], ws.ctl, sizeof(TrackCtl), hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess)
             rc = set_error(SSRS_ERR_HIP, "final read-back failed");
         else
-            memcpy(&host_ctl, &host_counts[32], sizeof(TrackCtl));
+            memcpy(&host_ctl, &host_counts[128], sizeof(TrackCtl));
     } else {
         (void)hipStreamSynchronize(st);
     }
