@@ -23,6 +23,8 @@ struct AmgHierarchy {
     std::vector<AmgLevel> levels;
     double *dense_inv = nullptr;   // inverse of the last level when it is small
     size_t workspace_used = 0;
+    void *graph_exec = nullptr;    // hipGraphExec_t of one captured cycle (NULL: direct launches)
+    bool graph_tried = false;
     int strong_rounds = 4;         // matching rounds restricted to strong couplings (of 8)
     int kdepth = 0;                // coarse levels 1..kdepth use the K-cycle (0 = V-cycle)
     int sweeps = 1;                // pairs of Jacobi sweeps before and after the coarse correction
@@ -34,5 +36,7 @@ int amg_setup(AmgHierarchy &h, const double *cond, const uint8_t *fixed, int row
               void *workspace, size_t workspace_bytes, hipStream_t st);
 // out = M rhs (one V(2,2) cycle); rhs/out: vectors on the raster numbering
 void amg_apply(AmgHierarchy &h, const double *rhs, double *out, hipStream_t st);
+// Frees host-side resources (the captured graph); device memory is the caller's.
+void amg_release(AmgHierarchy &h);
 
 }  // namespace ssrs

@@ -25,6 +25,8 @@
 #include <hipcub/hipcub.hpp>
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -440,15 +442,22 @@ __global__ __launch_bounds__(kBlock) void k_gj_finish(const double *__restrict__
         inv[e] = aug[static_cast<size_t>(i) * 2 * n + n + j] / aug[static_cast<size_t>(i) * 2 * n + i];
     }
 }
+// x = inv * b on the last level: one wave per row, lanes stride the row
+// (coalesced), shuffle reduction.  (One thread per row walked 800 strided
+// loads serially and was ~40 % of a whole V-cycle at 500 x 600.)
 __global__ __launch_bounds__(kBlock) void k_dense_apply(const double *__restrict__ inv,
                                                        const double *__restrict__ b, int n,
                                                        double *__restrict__ x)
 {
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        double s = 0.0;
-        for (int j = 0; j < n; ++j) s += inv[static_cast<size_t>(i) * n + j] * b[j];
-        x[i] = s;
-    }
+    const int lane = threadIdx.x & 63;
+    const int row = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    if (row >= n) return;
+    const double *r = inv + static_cast<size_t>(row) * n;
+    double s = 0.0;
+    for (int j = lane; j < n; j += 64) s += r[j] * b[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if (lane == 0) x[row] = s;
 }
 
 __global__ void k_copy(const double *__restrict__ a, double *__restrict__ b, size_t n)
@@ -752,7 +761,8 @@ static void cycle(AmgHierarchy &h, size_t lev, hipStream_t st)
     const int n = L.n, g = grid_for(n);
     if (lev + 1 == h.levels.size()) {
         if (h.dense_inv) {
-            hipLaunchKernelGGL(k_dense_apply, dim3(g), dim3(kBlock), 0, st, h.dense_inv, L.b, n, L.x);
+            hipLaunchKernelGGL(k_dense_apply, dim3(grid_for(static_cast<size_t>(n) * 64)), dim3(kBlock), 0, st,
+                               h.dense_inv, L.b, n, L.x);
         } else {                                   // stalled coarsening: relax
             hipLaunchKernelGGL(k_jacobi_first, dim3(g), dim3(kBlock), 0, st, L.dinv, L.b, n, L.x);
             for (int s = 0; s < 20; ++s) {
@@ -809,11 +819,54 @@ static void solve_level(AmgHierarchy &h, size_t lev, hipStream_t st)
     hipLaunchKernelGGL(k_copy, dim3(g), dim3(256), 0, st, L.xt, L.x, static_cast<size_t>(n));
 }
 
+// The V-cycle is ~10 levels x ~8 small kernels: on the coarse levels it is launch
+// bound (0.9 ms per PCG iteration at 500 x 600 was mostly launch gaps).  Its
+// structure and every pointer are fixed after setup, so the whole cycle is
+// captured once into a hipGraph and replayed; rhs/out staging stays outside.
+// Capture needs a real (non-null) stream; on the null stream, or if capture
+// fails, the kernels are launched directly.
+static void ensure_graph(AmgHierarchy &h, hipStream_t st)
+{
+    if (h.graph_tried) return;
+    h.graph_tried = true;
+    if (st == nullptr) return;
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) {
+        if (std::getenv("SSRS_PROGRESS")) fprintf(stderr, "[amg] begin capture failed: %s\n", hipGetErrorString(e));
+        (void)hipGetLastError();
+        return;
+    }
+    cycle(h, 0, st);
+    e = hipStreamEndCapture(st, &graph);
+    if (e != hipSuccess || graph == nullptr) {
+        if (std::getenv("SSRS_PROGRESS")) fprintf(stderr, "[amg] end capture failed: %s\n", hipGetErrorString(e));
+        (void)hipGetLastError();
+        return;
+    }
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (e == hipSuccess) h.graph_exec = exec;
+    else (void)hipGetLastError();
+    if (std::getenv("SSRS_PROGRESS"))
+        fprintf(stderr, "[amg] V-cycle graph: %s\n", e == hipSuccess ? "captured" : hipGetErrorString(e));
+    (void)hipGraphDestroy(graph);
+}
+
+void amg_release(AmgHierarchy &h)
+{
+    if (h.graph_exec) (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(h.graph_exec));
+    h.graph_exec = nullptr;
+}
+
 void amg_apply(AmgHierarchy &h, const double *rhs, double *out, hipStream_t st)
 {
     AmgLevel &L = h.levels[0];
+    ensure_graph(h, st);
     hipLaunchKernelGGL(k_copy, dim3(grid_for(L.n)), dim3(256), 0, st, rhs, L.b, static_cast<size_t>(L.n));
-    cycle(h, 0, st);
+    if (h.graph_exec == nullptr ||
+        hipGraphLaunch(static_cast<hipGraphExec_t>(h.graph_exec), st) != hipSuccess)
+        cycle(h, 0, st);
     hipLaunchKernelGGL(k_copy, dim3(grid_for(L.n)), dim3(256), 0, st, L.x, out, static_cast<size_t>(L.n));
 }
 

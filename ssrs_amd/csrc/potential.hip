@@ -364,7 +364,19 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
     SSRS_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0,
                  "ssrs_potential_solve: workspace must be 256-byte aligned");
     SSRS_REQUIRE(rel_tol > 0.0 && max_iterations > 0, "ssrs_potential_solve: bad tolerance / iteration cap");
+    // The solve is synchronous (it returns after its last kernel), so when the caller
+    // hands over the null stream the work runs on a private stream instead: graph
+    // capture of the V-cycle needs a capturable stream.  Caller order is kept by an
+    // event wait at entry and a stream sync at exit.
     hipStream_t st = as_stream(stream);
+    if (st == nullptr) {
+        static thread_local hipStream_t own = nullptr;
+        if (!own && hipStreamCreateWithFlags(&own, hipStreamNonBlocking) != hipSuccess) own = nullptr;
+        if (own) {
+            SSRS_HIP_CHECK(hipStreamSynchronize(nullptr));   // everything queued before the call
+            st = own;
+        }
+    }
     const size_t n = static_cast<size_t>(rows) * cols;
     char *base = static_cast<char *>(workspace);
     Scalars *sc = reinterpret_cast<Scalars *>(base);
@@ -376,6 +388,10 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
     // right-preconditioned BiCGStab: M = one AMG V-cycle of the symmetric operator
     const bool use_amg = (flags & SSRS_SOLVE_NO_AMG) == 0;
     AmgHierarchy amg;
+    struct AmgGuard {            // the captured graph is host state: free it on every exit
+        AmgHierarchy &h;
+        ~AmgGuard() { amg_release(h); }
+    } amg_guard{amg};
     amg.sweeps = 1 + ((flags >> 4) & 7);
     amg.kdepth = (flags & SSRS_SOLVE_K_CYCLE) ? 3 : 0;
     amg.strong_rounds = ((flags >> 8) & 15) ? ((flags >> 8) & 15) : 4;
@@ -383,7 +399,7 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
         char *amg_base = base + 10 * vec_bytes(n);
         amg_base = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(amg_base) + 255) / 256 * 256);
         const size_t amg_bytes = static_cast<size_t>(static_cast<char *>(workspace) + workspace_bytes - amg_base);
-        const int rc = amg_setup(amg, conductivity, fixed_mask, rows, cols, amg_base, amg_bytes, as_stream(stream));
+        const int rc = amg_setup(amg, conductivity, fixed_mask, rows, cols, amg_base, amg_bytes, st);
         if (rc != SSRS_OK) return rc;
     }
     StencilArgs a{conductivity, fixed_mask, rows, cols, use_amg ? 1 : 0, 1};
