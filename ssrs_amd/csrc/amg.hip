@@ -460,6 +460,11 @@ __global__ __launch_bounds__(kBlock) void k_dense_apply(const double *__restrict
     if (lane == 0) x[row] = s;
 }
 
+__global__ __launch_bounds__(kBlock) void k_axpy1(const double *__restrict__ a, int n, double *__restrict__ x)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) x[i] += a[i];
+}
+
 __global__ void k_copy(const double *__restrict__ a, double *__restrict__ b, size_t n)
 {
     for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n;
@@ -761,8 +766,14 @@ static void cycle(AmgHierarchy &h, size_t lev, hipStream_t st)
     const int n = L.n, g = grid_for(n);
     if (lev + 1 == h.levels.size()) {
         if (h.dense_inv) {
-            hipLaunchKernelGGL(k_dense_apply, dim3(grid_for(static_cast<size_t>(n) * 64)), dim3(kBlock), 0, st,
-                               h.dense_inv, L.b, n, L.x);
+            // x = inv b, then one step of iterative refinement against the sparse
+            // operator: the Gauss-Jordan inverse of a matrix whose entries span
+            // 1e-10 .. 1 is only accurate to a few digits
+            const int gd = grid_for(static_cast<size_t>(n) * 64);
+            hipLaunchKernelGGL(k_dense_apply, dim3(gd), dim3(kBlock), 0, st, h.dense_inv, L.b, n, L.x);
+            hipLaunchKernelGGL(k_residual, dim3(g), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.b, L.x, n, L.r);
+            hipLaunchKernelGGL(k_dense_apply, dim3(gd), dim3(kBlock), 0, st, h.dense_inv, L.r, n, L.xt);
+            hipLaunchKernelGGL(k_axpy1, dim3(g), dim3(kBlock), 0, st, L.xt, n, L.x);
         } else {                                   // stalled coarsening: relax
             hipLaunchKernelGGL(k_jacobi_first, dim3(g), dim3(kBlock), 0, st, L.dinv, L.b, n, L.x);
             for (int s = 0; s < 20; ++s) {
