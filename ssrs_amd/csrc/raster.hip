@@ -115,10 +115,34 @@ __global__ __launch_bounds__(kBlock) void k_slope_aspect(
     }
 }
 
+// Thresholded updraft with the two divisions folded into host constants
+// (v / thr -> v * inv_thr, . / (e - 1) -> . * scale): <= 2 ulp from the
+// reference expression, inside the 1e-12 tolerance the tests state.
+__device__ __forceinline__ double usable_updraft_fast(double v, double thr, double inv_thr,
+                                                      double scale)
+{
+    double f = 0.0;
+    if (v > 1e-02) {
+        if (v > thr) {
+            f = v;
+        } else {
+            const double y = v * inv_thr;
+            const double y2 = y * y;
+            f = scale * (exp((y2 * y2) * y) - 1.0);       // thr (exp((v/thr)^5) - 1) / (e - 1)
+        }
+    }
+    return f;
+}
+
+struct FusedArgs {
+    double d, d2;             // 8 res and its square
+    double wspeed, cos_w, sin_w, min_val;
+    double thr, inv_thr, scale;
+};
+
 template <typename Tin>
 __global__ __launch_bounds__(kBlock) void k_updraft_from_dem(
-    const Tin *__restrict__ dem, double res, double wspeed, double cos_w, double sin_w,
-    double min_val, float *__restrict__ orograph, double thr, double em1,
+    const Tin *__restrict__ dem, FusedArgs fa, float *__restrict__ orograph,
     double *__restrict__ usable, int rows, int cols, int tiles_x, int ntiles)
 {
     __shared__ double tile[LW * LH];
@@ -128,31 +152,48 @@ __global__ __launch_bounds__(kBlock) void k_updraft_from_dem(
     const int lc = threadIdx.x % TW + 1;
     const int c = c0 + lc - 1;
     if (c >= cols) return;
-    for (int lr = threadIdx.x / TW + 1; lr <= TH; lr += kBlock / TW) {
+    // each wave owns TH/4 consecutive rows of the tile and slides a 3 x 3 window
+    // down its column: 3 new LDS reads per cell instead of 8
+    constexpr int kRowsPerWave = TH / (kBlock / TW);
+    const int lr0 = (threadIdx.x / TW) * kRowsPerWave + 1;
+    const double *q = tile + (lr0 - 1) * LW + lc;
+    double m_l = q[-1], m_c = q[0], m_r = q[1];               // row lr - 1
+    double z_l = q[LW - 1], z_c = q[LW], z_r = q[LW + 1];     // row lr
+    for (int lr = lr0; lr < lr0 + kRowsPerWave; ++lr) {
         const int r = r0 + lr - 1;
         if (r >= rows) break;
+        const double *p = tile + (lr + 1) * LW + lc;
+        const double p_l = p[-1], p_c = p[0], p_r = p[1];     // row lr + 1
         double w = 0.0;
         if (r > 0 && c > 0 && r < rows - 1 && c < cols - 1) {
-            double dzdx, dzdy;
-            horn(tile, lr, lc, res, dzdx, dzdy);
-            // sin(slope) = g / sqrt(1 + g^2), g = |grad|      (slope = atan g)
-            // cos(aspect - wdirn) = -(dzdy cos w + dx sin w) / g'
-            //   with dx = dzdx (1e-10 when exactly 0, layers.py:124) and
-            //   g' = sqrt(dx^2 + dzdy^2); identity from aspect = 180 - atan(dzdy/dx)
-            //   + 90 sign(dx).
-            const double g2 = dzdx * dzdx + dzdy * dzdy;
-            const double dx = dzdx == 0.0 ? 1e-10 : dzdx;
-            const double proj = -(dzdy * cos_w + dx * sin_w);
-            if (proj > 0.0 && g2 > 0.0) {
-                const double gp2 = dx * dx + dzdy * dzdy;
-                w = wspeed * (proj * sqrt(g2 / (gp2 * (1.0 + g2))));
+            // un-normalised Horn sums X = 8 res dz_dx, Y = 8 res dz_dy in the
+            // reference's operand order (layers.py:78-90; "x" = row axis)
+            const double X = (p_r + 2 * p_c + p_l) - (m_r + 2 * m_c + m_l);
+            const double Y = (m_r + 2 * z_r + p_r) - (m_l + 2 * z_l + p_l);
+            if (X != 0.0) {
+                // sin(slope) cos(aspect - wdirn) = -(dz_dy cos w + dz_dx sin w) / sqrt(1 + g^2)
+                //                                 = -(Y cos w + X sin w) / sqrt(d^2 + X^2 + Y^2)
+                // (sin(atan g) = g / sqrt(1 + g^2); cos(aspect - w) from aspect =
+                //  180 - atan(dz_dy/dz_dx) + 90 sign(dz_dx)): no trig, no division.
+                const double P = -(Y * fa.cos_w + X * fa.sin_w);
+                if (P > 0.0) w = fa.wspeed * (P * rsqrt(fa.d2 + (X * X + Y * Y)));
+            } else {
+                // dz_dx == 0: the reference substitutes 1e-10 for the aspect only
+                // (layers.py:124) -- rare, evaluated in the explicit form
+                const double dzdy = Y / fa.d, dx = 1e-10;
+                const double g2 = dzdy * dzdy, gp2 = dx * dx + g2;
+                const double proj = -(dzdy * fa.cos_w + dx * fa.sin_w);
+                if (proj > 0.0 && g2 > 0.0) w = fa.wspeed * (proj * sqrt(g2 / (gp2 * (1.0 + g2))));
             }
         }
-        w = w > min_val ? w : min_val;
+        w = w > fa.min_val ? w : fa.min_val;
         const size_t i = static_cast<size_t>(r) * cols + c;
         const float w32 = static_cast<float>(w);
         if (orograph) orograph[i] = w32;
-        if (usable) usable[i] = usable_updraft(static_cast<double>(w32), thr, em1);
+        if (usable)
+            usable[i] = usable_updraft_fast(static_cast<double>(w32), fa.thr, fa.inv_thr, fa.scale);
+        m_l = z_l; m_c = z_c; m_r = z_r;
+        z_l = p_l; z_c = p_c; z_r = p_r;
     }
 }
 
@@ -311,22 +352,28 @@ extern "C" int ssrs_updraft_from_dem(const void *dem, int dem_type, double res,
     SSRS_REQUIRE(res > 0.0, "ssrs_updraft_from_dem: res must be > 0");
     SSRS_REQUIRE(dem_type == SSRS_F32 || dem_type == SSRS_F64,
                  "ssrs_updraft_from_dem: bad element type");
-    SSRS_REQUIRE(!(usable && threshold < 0.0),
-                 "ssrs_updraft_from_dem: usable requested with threshold < 0");
+    SSRS_REQUIRE(!(usable && !(threshold > 0.0)),
+                 "ssrs_updraft_from_dem: usable requested without a positive threshold");
     if (!orograph && !usable) return SSRS_OK;
     const int tx = (cols + TW - 1) / TW, ty = (rows + TH - 1) / TH, nt = tx * ty;
     const double w = wdirn * kPi / 180.0;
-    const double cw = cos(w), sw = sin(w);
-    const double em1 = exp(1.0) - 1.0;
+    FusedArgs fa;
+    fa.d = 8 * res;
+    fa.d2 = fa.d * fa.d;
+    fa.wspeed = wspeed;
+    fa.cos_w = cos(w);
+    fa.sin_w = sin(w);
+    fa.min_val = min_val;
+    fa.thr = threshold;
+    fa.inv_thr = threshold > 0.0 ? 1.0 / threshold : 0.0;
+    fa.scale = threshold > 0.0 ? threshold / (exp(1.0) - 1.0) : 0.0;
     hipStream_t st = as_stream(stream);
     if (dem_type == SSRS_F64)
         hipLaunchKernelGGL((k_updraft_from_dem<double>), dim3(nt), dim3(kBlock), 0, st,
-                           static_cast<const double *>(dem), res, wspeed, cw, sw, min_val,
-                           orograph, threshold, em1, usable, rows, cols, tx, nt);
+                           static_cast<const double *>(dem), fa, orograph, usable, rows, cols, tx, nt);
     else
         hipLaunchKernelGGL((k_updraft_from_dem<float>), dim3(nt), dim3(kBlock), 0, st,
-                           static_cast<const float *>(dem), res, wspeed, cw, sw, min_val,
-                           orograph, threshold, em1, usable, rows, cols, tx, nt);
+                           static_cast<const float *>(dem), fa, orograph, usable, rows, cols, tx, nt);
     SSRS_HIP_CHECK(hipGetLastError());
     return SSRS_OK;
 }
