@@ -197,6 +197,31 @@ __global__ __launch_bounds__(kBlock) void k_updraft_from_dem(
     }
 }
 
+// sin / cos of an angle given in DEGREES.  The reference converts to radians
+// first ((a - w) * pi / 180, two roundings) and calls libm; ocml's f64 sin/cos
+// carry a Payne-Hanek path these bounded arguments never need and made
+// k_orographic ALU-bound (170-180 us at C2).  Here the quadrant is removed
+// exactly in degrees (x - 90 k is exact for |x| < 2^52), the remainder
+// |r| <= 45 deg goes through the classic minimax kernels on [-pi/4, pi/4]
+// (fdlibm k_sin / k_cos coefficients, < 1-2 ulp).  Result within ~1e-15 of the
+// reference's value, far inside the 1-f32-ulp tolerance of the orograph.
+__device__ __forceinline__ void sincos_deg(double x, double &sn, double &cs)
+{
+    const double kq = rint(x * (1.0 / 90.0));
+    const double r = x - 90.0 * kq;                    // exact
+    const double t = r * (kPi / 180.0);
+    const double z = t * t;
+    const double ps = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
+                      z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+    const double pc = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                      z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+    const double s0 = t + (t * z) * ps;
+    const double c0 = 1.0 - (0.5 * z - (z * z) * pc);
+    const int q = static_cast<int>(kq) & 3;
+    sn = (q == 0) ? s0 : (q == 1) ? c0 : (q == 2) ? -s0 : -c0;
+    cs = (q == 0) ? c0 : (q == 1) ? -s0 : (q == 2) ? -c0 : s0;
+}
+
 // ---------------------------------------------------------------------------
 // Elementwise orographic updraft, VEC consecutive cells per thread (16-byte
 // accesses for f32 rasters), batched over wind cases.
@@ -226,7 +251,10 @@ __global__ __launch_bounds__(kBlock) void k_orographic(
         double sin_s[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j)
-            sin_s[j] = sin(static_cast<double>(s.v[j]) * kPi / 180.0);
+        {
+            double unused;
+            sincos_deg(static_cast<double>(s.v[j]), sin_s[j], unused);
+        }
         for (int b = 0; b < batch; ++b) {
             const size_t o = static_cast<size_t>(b) * nvec + i;
             Pack<Tw, VEC> ws, wd;
@@ -240,7 +268,8 @@ __global__ __launch_bounds__(kBlock) void k_orographic(
             for (int j = 0; j < VEC; ++j) {
                 const double spd = UNIFORM ? uni.wspeed[b] : static_cast<double>(ws.v[j]);
                 const double dir = UNIFORM ? uni.wdirn[b] : static_cast<double>(wd.v[j]);
-                double ad = cos((static_cast<double>(a.v[j]) - dir) * kPi / 180.0);
+                double ad, unused;
+                sincos_deg(static_cast<double>(a.v[j]) - dir, unused, ad);
                 ad = ad > 0.0 ? ad : 0.0;                      // np.maximum(0., .)
                 double w = spd * (sin_s[j] * ad);
                 w = w > min_val ? w : min_val;
