@@ -317,3 +317,32 @@ def test_c2_scale_properties(gpu):
                                    pot.cpu().numpy(), seed=30, want_traj=False)
     assert np.array_equal(a.lengths[:m].cpu().numpy(), ref['lengths'])
     assert np.array_equal(a.ends[:m].cpu().numpy(), ref['ends'])
+
+
+def test_binned_histogram_path_with_trajectories(gpu):
+    """>= 8192 tracks switches the histogram to the visit-buffer + LDS-binning
+    kernel (k_bin_visits); with trajectories requested at the same time every
+    output must still equal the C oracle's, and the A/B switches must agree."""
+    from ssrs_amd import movmodel, presence
+    from oracle import c_oracle
+    rows, cols = 300, 320
+    upd, pot = _random_field_case(rows, cols, 77)
+    rng = np.random.default_rng(5)
+    n = 10000
+    starts = np.stack([rng.integers(2, 40, n), rng.integers(0, cols, n)], 1)
+    ref = c_oracle.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=11,
+                                   track_id_base=5)
+    got = movmodel.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=11,
+                                   track_id_base=5, use_table=True, want_tracks=True)
+    assert np.array_equal(got.lengths.cpu().numpy(), ref['lengths'])
+    assert np.array_equal(got.ends.cpu().numpy(), ref['ends'])
+    assert np.array_equal(got.hist.cpu().numpy().view(np.uint32), ref['hist'])
+    assert np.array_equal(got.traj.cpu().numpy(), np.concatenate(ref['tracks']))
+    # histogram rebuilt from the stored trajectories (K3' kernel) agrees as well
+    again = presence.compute_presence_counts(got.traj, (rows, cols))
+    assert torch.equal(again, got.hist)
+    for kw in (dict(binning=False), dict(schedule=False), dict(use_table=False)):
+        kw = dict(dict(use_table=True), **kw)
+        alt = movmodel.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=11,
+                                       track_id_base=5, **kw)
+        assert torch.equal(alt.hist, got.hist) and torch.equal(alt.lengths, got.lengths)
