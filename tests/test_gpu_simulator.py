@@ -149,3 +149,17 @@ def test_seasonal_mode_lattice_wind_and_thermals(gpu, tmp_path):
             assert os.path.exists(os.path.join(sim.mode_data_dir, f'{cid}_d0_t75_drw_r{real}_tracks.pkl'))
     out = sim.compute_presence_map(radius=300.)
     assert out.shape == (60, 80) and out.max() == 1.0
+
+
+def test_presence_map_from_saved_tracks_matches_in_memory(gpu, tmp_path):
+    """plot_presence_map in a fresh process state reads <id>_tracks.pkl like the
+    reference (simulator.py:525-529); the map must equal the one computed from
+    the device histogram kept by simulate_tracks."""
+    from ssrs_amd import Simulator
+    cfg = make_config(tmp_path, run_name='pm', track_count=150)
+    sim = Simulator(cfg, terrain='synthetic')
+    sim.simulate_tracks()
+    first = sim.compute_presence_map(radius=400.)
+    sim2 = Simulator(cfg, terrain='synthetic')      # same out_dir: finds orograph/potential/tracks
+    second = sim2.compute_presence_map(radius=400.)
+    assert np.array_equal(first, second)
