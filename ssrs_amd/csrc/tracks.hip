@@ -208,14 +208,16 @@ __device__ __forceinline__ int choose_table_fast(const double *t, uint32_t mask,
     const double ut = u * acc;
     const double band = ut * 0x1p-46;
     int idx = 0;
-    bool near = !(acc > 0.0);
+    double closest = __builtin_inf();            // min_k |C_k - u C_8|
 #pragma unroll
     for (int j = 0; j < 7; ++j) {               // k = 8 is never counted: cdf_8 = 1 > u
         const double d = c[j] - ut;
         const int le = d <= 0.0 ? 1 : 0;
         idx += (j == 3) ? 2 * le : le;          // cdf_4 == cdf_3 (centre weight is 0)
-        near |= !(fabs(d) > band);
+        closest = fmin(closest, fabs(d));
     }
+    // NaN / inf rows: acc > 0 is false for NaN; inf gives band = inf >= closest
+    const bool near = !(acc > 0.0) || !(closest > band);
     return near ? -1 : idx;
 }
 
@@ -458,7 +460,9 @@ __global__ __launch_bounds__(kBlock) void k_tracks_init(
     state[t] = s;
 }
 
-template <int MODE>
+// LEAN = the production case (memory_parameter == 1, no trajectory output): the
+// trajectory stores, the history loop and the running mask are compiled out.
+template <int MODE, bool LEAN = false>
 __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
 {
     TrackCtl *ctl = a.ctl;
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
                             static_cast<long long>(a.launch) * a.steps;
     const int release = rel64 > 0x7fffffffLL ? 0x7fffffff : (rel64 < 0 ? 0 : static_cast<int>(rel64));
     const unsigned long long track = a.track_base + static_cast<unsigned long long>(t);
-    const long long toff = (a.traj && active) ? a.traj_off[t] : 0;
+    const long long toff = (!LEAN && a.traj && active) ? a.traj_off[t] : 0;
     uint32_t pend_a = 0, pend_b = 0;   // words (2,3) of the current Philox block
     bool have_pending = false;
     uint32_t moved = 0;
@@ -545,7 +549,7 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
                 const double u = words_to_uniform(wa, wb);
                 // ---- direction memory (movmodel.py:307-309)
                 uint32_t mask = kAllButCentre;
-                if (a.memory == 1) {                 // the reference default: last move only
+                if (LEAN || a.memory == 1) {         // the reference default: last move only
                     mask = restriction_of(dirs & 0xFu);
                 } else if (a.memory == 0) {
                     mask = run;
@@ -580,12 +584,12 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
                 row = er + idx / 3 - 1;
                 col = ec + idx % 3 - 1;
                 dirs = (dirs << 4) | static_cast<uint32_t>(idx);
-                if (a.memory == 0) run &= restriction_of(static_cast<uint32_t>(idx));
+                if (!LEAN && a.memory == 0) run &= restriction_of(static_cast<uint32_t>(idx));
                 ++k;
                 ++moved;
                 stepped = true;
                 loop_head();                       // head of the NEXT step
-                if (a.traj)
+                if (!LEAN && a.traj)
                     reinterpret_cast<uint32_t *>(a.traj)[toff + k] =
                         static_cast<uint32_t>(row & 0xFFFF) | (static_cast<uint32_t>(col) << 16);
             }
@@ -912,6 +916,7 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
     a.state = ws.state; a.ctl = ws.ctl; a.steps = S;
     a.fast = ((p->flags & SSRS_TRACKS_EXACT_ONLY) == 0 && p->scaling_parameter == 1.0) ? 1 : 0;
     a.coherent = coherent ? 1 : 0;
+    const bool lean = p->memory_parameter == 1 && traj == nullptr;
     // binning needs the coherent front (a step's visits fall into a few rows)
     // The binning kernel runs on the SAME stream, after its stepper launch.  Running it
     // on a side stream to overlap the next launch was measured and rejected: its
@@ -965,7 +970,10 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
                 if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); ev_prof.push_back(e); }
             }
             switch (mode) {
-            case MODE_TABLE: hipLaunchKernelGGL(k_step_tracks<MODE_TABLE>, dim3(blocks), dim3(kBlock), 0, st, a); break;
+            case MODE_TABLE:
+                if (lean) hipLaunchKernelGGL((k_step_tracks<MODE_TABLE, true>), dim3(blocks), dim3(kBlock), 0, st, a);
+                else hipLaunchKernelGGL((k_step_tracks<MODE_TABLE, false>), dim3(blocks), dim3(kBlock), 0, st, a);
+                break;
             case MODE_FLUIDFLOW: hipLaunchKernelGGL(k_step_tracks<MODE_FLUIDFLOW>, dim3(blocks), dim3(kBlock), 0, st, a); break;
             case MODE_UPDRAFT: hipLaunchKernelGGL(k_step_tracks<MODE_UPDRAFT>, dim3(blocks), dim3(kBlock), 0, st, a); break;
             default: hipLaunchKernelGGL(k_step_tracks<MODE_PRIOR>, dim3(blocks), dim3(kBlock), 0, st, a); break;
