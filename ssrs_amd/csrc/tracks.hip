@@ -670,9 +670,12 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_visits(const uint32_t *__re
     if (threadIdx.x == 0) s_first = 0xFFFFFFFFu;
     for (int k = threadIdx.x; k < wrows * cols; k += kBinThreads) bins[k] = 0;
     __syncthreads();
-    // window origin: the smallest visited cell's row
+    // window origin: the row of the smallest visited cell among a SAMPLE of the
+    // slots (4 per thread, spread over the list).  A full pass would read the
+    // step's visits twice; visits below the sampled origin simply count as strays.
     uint32_t mn = 0xFFFFFFFFu;
-    for (uint32_t j = threadIdx.x; j < nslots; j += kBinThreads) {
+    const uint32_t stride4 = nslots / 4 > 0 ? nslots / 4 : 1;
+    for (uint32_t q = 0, j = threadIdx.x; q < 4 && j < nslots; ++q, j += stride4) {
         const uint32_t c = v[j];
         mn = c < mn ? c : mn;
     }
@@ -683,9 +686,29 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_visits(const uint32_t *__re
     }
     if ((threadIdx.x & 63) == 0 && mn != 0xFFFFFFFFu) atomicMin(&s_first, mn);
     __syncthreads();
+    if (s_first == 0xFFFFFFFFu) {
+        // the sample saw only idle slots (sparse late launches): look at all of them
+        __syncthreads();
+        mn = 0xFFFFFFFFu;
+        for (uint32_t j = threadIdx.x; j < nslots; j += kBinThreads) {
+            const uint32_t c = v[j];
+            mn = c < mn ? c : mn;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t o = __shfl_down(mn, off);
+            mn = o < mn ? o : mn;
+        }
+        if ((threadIdx.x & 63) == 0 && mn != 0xFFFFFFFFu) atomicMin(&s_first, mn);
+        __syncthreads();
+    }
     const uint32_t first = s_first;
     if (first == 0xFFFFFFFFu) return;                  // nobody moved in this step
-    const uint32_t base = (first / cols) * cols;       // first cell of the window
+    // first cell of the window: one row below the sampled minimum when the window
+    // has room, so that a slightly lagging track is still binned
+    uint32_t brow = first / cols;
+    if (wrows >= 3 && brow > 0) --brow;
+    const uint32_t base = brow * cols;
     const uint32_t wcells = static_cast<uint32_t>(wrows) * cols;
     uint32_t stray = 0;
     for (uint32_t j = threadIdx.x; j < nslots; j += kBinThreads) {
