@@ -345,6 +345,8 @@ struct alignas(16) TrackCtl {
     unsigned long long steps;    // total moves taken
     unsigned long long strays;   // visits the binning kernel could not place in its LDS window
     unsigned long long pad;
+    double prior[9];             // directional prior of this call (read by the slow paths)
+    double pad2;
 };
 
 // Coherent schedule.  Tracks are independent, so the order in which lanes pick
@@ -396,7 +398,7 @@ struct StepArgs {
     int rows, cols, burnin, memory;
     long long max_k;
     double nu;
-    double prior[9];
+    const double *prior;         // 9 doubles in device memory (kept out of the SGPR budget)
     const double *updraft;
     const float *potential;
     const double *table;
@@ -567,7 +569,10 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
                     if (a.fast) idx = choose_table_fast(tt, mask, u);
                     if (idx < 0) {
                         const double w[9] = {tt[0], tt[1], tt[2], tt[3], 0.0, tt[4], tt[5], tt[6], tt[7]};
-                        idx = choose_move(w, a.prior, a.nu, mask, u, false);
+                        double pr[9];
+#pragma unroll
+                        for (int j = 0; j < 9; ++j) pr[j] = a.prior[j];
+                        idx = choose_move(w, pr, a.nu, mask, u, false);
                     }
                 } else {
                     double w[9];
@@ -579,7 +584,10 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
 #pragma unroll
                         for (int j = 0; j < 9; ++j) w[j] = a.prior[j];
                     }
-                    idx = choose_move(w, a.prior, a.nu, mask, u, a.fast != 0);
+                    double pr[9];
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) pr[j] = a.prior[j];
+                    idx = choose_move(w, pr, a.nu, mask, u, a.fast != 0);
                 }
                 row = er + idx / 3 - 1;
                 col = ec + idx % 3 - 1;
@@ -895,6 +903,7 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
                                                    : MODE_PRIOR);
 
     SSRS_HIP_CHECK(hipMemsetAsync(ws.ctl, 0, sizeof(TrackCtl), st));
+    SSRS_HIP_CHECK(hipMemcpyAsync(ws.ctl->prior, p->prior, 9 * sizeof(double), hipMemcpyHostToDevice, st));
     hipEvent_t ev_first = nullptr, ev_last = nullptr;
     SSRS_HIP_CHECK(hipEventCreate(&ev_first));
     SSRS_HIP_CHECK(hipEventCreate(&ev_last));
@@ -931,7 +940,7 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
     StepArgs a = {};
     a.rows = p->rows; a.cols = p->cols; a.burnin = p->burnin; a.memory = p->memory_parameter;
     a.max_k = p->max_moves; a.nu = p->scaling_parameter;
-    for (int j = 0; j < 9; ++j) a.prior[j] = p->prior[j];
+    a.prior = ws.ctl->prior;
     a.updraft = updraft; a.potential = potential; a.table = table;
     a.seed = seed; a.track_base = track_id_base;
     a.hist = hist; a.end_rc = end_rc; a.lengths = lengths; a.traj = traj;
