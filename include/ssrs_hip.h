@@ -183,7 +183,10 @@ size_t ssrs_tracks_workspace_bytes(int64_t ntracks);
  *   hist       uint32 (rows, cols), ACCUMULATED (+1 per trajectory point), or NULL
  *   end_rc     int16 (ntracks, 2) last point, or NULL
  *   lengths    int32 (ntracks) number of trajectory points, or NULL
- *   traj       int16 pairs, track t at traj[2*traj_offsets[t] ...], or NULL
+ *   traj       int16 pairs, track t at traj[2*traj_offsets[t] ...], or NULL;
+ *              traj_offsets int64 (ntracks + 1): exclusive prefix sums of the
+ *              lengths of a previous call with the same arguments; points beyond
+ *              a track's room [offsets[t], offsets[t+1]) are dropped, never written
  *   workspace  device scratch of ssrs_tracks_workspace_bytes(ntracks)
  *   stats      [host] out, may be NULL */
 int ssrs_tracks_simulate(const SsrsTrackParams *params, const double *updraft,

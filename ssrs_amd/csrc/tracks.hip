@@ -77,6 +77,33 @@ __device__ __forceinline__ uint32_t restriction_of(uint32_t d)
     return static_cast<uint32_t>(v) & 0x1FFu;
 }
 
+// With memory_parameter == 1 (the reference default) every step after the first
+// has exactly THREE admissible cells.  candidates(d) = their positions in the
+// 8-entry table row (k with the centre removed), ascending, 3 bits each.
+constexpr uint32_t candidates(int d)
+{
+    uint32_t v = 0;
+    int n = 0;
+    for (int k = 0; k < 9 && n < 3; ++k)
+        if ((restriction(d) >> k) & 1u) v |= static_cast<uint32_t>(k < 4 ? k : k - 1) << (3 * n++);
+    return v;
+}
+constexpr uint64_t pack_candidates(int first, int count)
+{
+    uint64_t v = 0;
+    for (int i = 0; i < count; ++i) v |= static_cast<uint64_t>(candidates(first + i)) << (9 * i);
+    return v;
+}
+constexpr uint64_t kCandLo = pack_candidates(0, 7), kCandHi = pack_candidates(7, 2);
+static_assert(candidates(7) == (5u | (6u << 3) | (7u << 6)), "(1,0) -> table slots 5,6,7");
+static_assert(candidates(5) == (2u | (4u << 3) | (7u << 6)), "(0,1) -> k = 2,5,8 = slots 2,4,7");
+
+__device__ __forceinline__ uint32_t candidates_of(uint32_t d)
+{
+    const uint64_t v = d < 7 ? (kCandLo >> (9 * d)) : (kCandHi >> (9 * (d - 7)));
+    return static_cast<uint32_t>(v) & 0x1FFu;
+}
+
 // ------------------------------------------------------------------- uniform
 // rocRAND Philox4x32-10: key = seed, counter = (blk, track); one 4-word block
 // serves two steps.  The engine is built and dropped in registers (stateless).
@@ -219,6 +246,24 @@ __device__ __forceinline__ int choose_table_fast(const double *t, uint32_t mask,
     // NaN / inf rows: acc > 0 is false for NaN; inf gives band = inf >= closest
     const bool near = !(acc > 0.0) || !(closest > band);
     return near ? -1 : idx;
+}
+
+// The same decision when only three cells are admissible (their table values
+// wa, wb, wc in ascending k): masked entries add 0.0 to the running sum, so the
+// three partial sums ARE the masked row's cumulative sums, bit for bit.
+// Returns the position (0..2) of the chosen candidate or -1 (see above).
+__device__ __forceinline__ int choose_three_fast(double wa, double wb, double wc, double u)
+{
+    const double ca = wa + 0.0;                  // -0.0 -> +0.0 like the 0.0-seeded sum
+    const double cb = ca + wb;
+    const double acc = cb + wc;
+    const double ut = u * acc;
+    const double band = ut * 0x1p-46;
+    const double da = ca - ut, db = cb - ut;
+    const int sel = da > 0.0 ? 0 : (db > 0.0 ? 1 : 2);
+    const double closest = fmin(fmin(fabs(da), fabs(db)), fmin(ut, fabs(acc - ut)));
+    const bool near = !(acc > 0.0) || !(closest > band);
+    return near ? -1 : sel;
 }
 
 // Raw 3x3 move weights of movmodel.py:292-306 at an interior cell.
@@ -443,6 +488,9 @@ __global__ __launch_bounds__(kBlock) void k_tracks_init(
         const uint32_t pmin = ctl->par_min;
         delay = static_cast<uint32_t>(par) > pmin ? static_cast<uint32_t>(par) - pmin : 0u;
         if (delay > 0x7FFFFFu) delay = 0x7FFFFFu;
+        // even delays keep the parity of k wave-uniform: one Philox block serves two
+        // steps, and a wave with mixed parities would evaluate it on every iteration
+        delay &= ~1u;
     }
     s.aux = kAllButCentre | (delay << 9);
     if (row < 0 || col < 0 || row >= rows || col >= cols) {
@@ -490,6 +538,9 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
     const int release = rel64 > 0x7fffffffLL ? 0x7fffffff : (rel64 < 0 ? 0 : static_cast<int>(rel64));
     const unsigned long long track = a.track_base + static_cast<unsigned long long>(t);
     const long long toff = (!LEAN && a.traj && active) ? a.traj_off[t] : 0;
+    // room of this track in traj: a caller whose offsets do not come from this
+    // very simulation must not be able to make the kernel write out of bounds
+    const long long troom = (!LEAN && a.traj && active) ? a.traj_off[t + 1] - toff : 0;
     uint32_t pend_a = 0, pend_b = 0;   // words (2,3) of the current Philox block
     bool have_pending = false;
     uint32_t moved = 0;
@@ -517,8 +568,19 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
         }
     };
     double2 t0 = {0.0, 0.0}, t1 = t0, t2 = t0, t3 = t0;      // prefetched table entry
+    // LEAN: only the three admissible cells of the next step are fetched (the
+    // previous move is known when the fetch is issued), 24 B instead of 64 B
+    double ta = 0.0, tb = 0.0, tc = 0.0;
+    uint32_t cand = 0;
+    (void)ta; (void)tb; (void)tc; (void)cand;
     auto fetch_entry = [&]() {
-        if (MODE == MODE_TABLE) {
+        if (MODE == MODE_TABLE && LEAN) {
+            cand = candidates_of(dirs & 0xFu);
+            const double *src = a.table + (static_cast<size_t>(er) * a.cols + ec) * 8;
+            ta = src[cand & 7u];
+            tb = src[(cand >> 3) & 7u];
+            tc = src[cand >> 6];
+        } else if (MODE == MODE_TABLE) {
             const double2 *src = reinterpret_cast<const double2 *>(
                 a.table + (static_cast<size_t>(er) * a.cols + ec) * 8);
             t0 = src[0]; t1 = src[1]; t2 = src[2]; t3 = src[3];
@@ -564,11 +626,37 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
                 }
                 // ---- weights + decision
                 int idx = -1;
-                if (MODE == MODE_TABLE) {
+                if (MODE == MODE_TABLE && LEAN) {
+                    // first step of a track (no previous move: 8 admissible cells) and
+                    // near-ties go to the exact sequence on the full row
+                    if (a.fast && (dirs & 0xFu) != 4u) {
+                        const int sel = choose_three_fast(ta, tb, tc, u);
+                        const uint32_t slot = (cand >> (3 * (sel < 0 ? 0 : sel))) & 7u;
+                        idx = sel < 0 ? -1 : static_cast<int>(slot + (slot >= 4u ? 1u : 0u));
+                    }
+                    if (__builtin_expect(idx < 0, 0)) {
+                        const double *src = a.table + (static_cast<size_t>(er) * a.cols + ec) * 8;
+                        double o[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o[j] = __builtin_nontemporal_load(src + j);
+                        const double w[9] = {o[0], o[1], o[2], o[3], 0.0, o[4], o[5], o[6], o[7]};
+                        double pr[9];
+#pragma unroll
+                        for (int j = 0; j < 9; ++j) pr[j] = a.prior[j];
+                        idx = choose_move(w, pr, a.nu, mask, u, false);
+                    }
+                } else if (MODE == MODE_TABLE) {
                     const double tt[8] = {t0.x, t0.y, t1.x, t1.y, t2.x, t2.y, t3.x, t3.y};
                     if (a.fast) idx = choose_table_fast(tt, mask, u);
-                    if (idx < 0) {
-                        const double w[9] = {tt[0], tt[1], tt[2], tt[3], 0.0, tt[4], tt[5], tt[6], tt[7]};
+                    if (__builtin_expect(idx < 0, 0)) {
+                        // taken ~1e-12 of the time.  The empty asm makes the inputs opaque
+                        // INSIDE the branch: without it hipcc hoists ~100 instructions of the
+                        // exact path (clip / mask / NaN scan) above the branch into every step
+                        double o[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { o[j] = tt[j]; asm volatile("" : "+v"(o[j])); }
+                        asm volatile("" : "+v"(mask));
+                        const double w[9] = {o[0], o[1], o[2], o[3], 0.0, o[4], o[5], o[6], o[7]};
                         double pr[9];
 #pragma unroll
                         for (int j = 0; j < 9; ++j) pr[j] = a.prior[j];
@@ -597,7 +685,7 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
                 ++moved;
                 stepped = true;
                 loop_head();                       // head of the NEXT step
-                if (!LEAN && a.traj)
+                if (!LEAN && a.traj && k < troom)
                     reinterpret_cast<uint32_t *>(a.traj)[toff + k] =
                         static_cast<uint32_t>(row & 0xFFFF) | (static_cast<uint32_t>(col) << 16);
             }
