@@ -383,8 +383,14 @@ struct alignas(16) TrackState {
                      // (memory == 0); bits 9-31: release step (coherent schedule)
 };
 
+// Live tracks are kept in kXcd separate lists, one per XCD: blocks are dealt to
+// the XCDs round-robin (block b runs on XCD b % 8), so block b serves list b % 8
+// and a track stays on the XCD it was dealt to.  With the coherent schedule the
+// lists are contiguous bands of the across-track coordinate: the table rows a
+// band walks over are fetched into ONE XCD's L2 instead of all eight.
+constexpr int kXcd = 8;
 struct alignas(16) TrackCtl {
-    uint32_t count[4];           // live tracks entering launch i at count[i & 3]
+    uint32_t count[4][kXcd];     // live tracks of list x entering launch i at count[i & 3][x]
     uint32_t error;              // != 0: some start cell was outside the raster
     uint32_t par_min;            // smallest along-track start coordinate (schedule)
     unsigned long long steps;    // total moves taken
@@ -393,6 +399,8 @@ struct alignas(16) TrackCtl {
     double prior[9];             // directional prior of this call (read by the slow paths)
     double pad2;
 };
+
+static_assert(sizeof(TrackCtl) <= 128 * sizeof(uint32_t), "final read-back slot of pinned_counts()");
 
 // Coherent schedule.  Tracks are independent, so the order in which lanes pick
 // them up and the global step at which each one starts are free choices that
@@ -463,18 +471,21 @@ struct StepArgs {
     int coherent;                // tracks carry a release step in aux
     uint32_t *visits;            // [steps][visit_stride] visited cell per slot (K3 binning), or NULL
     long long visit_stride;
+    uint32_t cap;                // slots per XCD list (multiple of kBlock); list x = [x*cap, (x+1)*cap)
 };
 
 __global__ __launch_bounds__(kBlock) void k_tracks_init(
     const int32_t *__restrict__ start_rc, long long ntracks, int rows, int cols,
     uint32_t *hist, int16_t *traj, const long long *traj_off, int32_t *lengths,
-    int16_t *end_rc, TrackState *state, TrackCtl *ctl, PlanGeom g, int coherent)
+    int16_t *end_rc, TrackState *state, TrackCtl *ctl, PlanGeom g, int coherent, uint32_t cap)
 {
     const long long t = blockIdx.x * static_cast<long long>(kBlock) + threadIdx.x;
-    if (t == 0) {
-        ctl->count[0] = static_cast<uint32_t>(ntracks);
-        ctl->count[1] = ctl->count[2] = ctl->count[3] = 0;
-        ctl->steps = 0;
+    if (t < kXcd) {
+        // the first launch's list (sorted or identity) is cut into kXcd runs of cap slots
+        const long long left = ntracks - t * static_cast<long long>(cap);
+        ctl->count[0][t] = static_cast<uint32_t>(left < 0 ? 0 : (left > cap ? cap : left));
+        ctl->count[1][t] = ctl->count[2][t] = ctl->count[3][t] = 0;
+        if (t == 0) ctl->steps = 0;
     }
     if (t >= ntracks) return;
     const int row = start_rc[2 * t], col = start_rc[2 * t + 1];
@@ -517,13 +528,16 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
 {
     TrackCtl *ctl = a.ctl;
     const int in_slot = a.launch & 3, out_slot = (a.launch + 1) & 3;
-    const uint32_t nlive = ctl->count[in_slot];
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i == 0) ctl->count[(a.launch + 2) & 3] = 0;   // free slot of launch+1's output
+    const uint32_t xcd = blockIdx.x % kXcd;
+    const uint32_t nlive = ctl->count[in_slot][xcd];
+    const uint32_t il = (blockIdx.x / kXcd) * kBlock + threadIdx.x;   // position in list xcd
+    const uint32_t i = xcd * a.cap + il;                               // slot in the list arrays
+    if (blockIdx.x == 0 && threadIdx.x < kXcd)
+        ctl->count[(a.launch + 2) & 3][threadIdx.x] = 0;   // free slot of launch+1's output
     // whole waves past the live list leave at once (wave-uniform)
-    if ((i & ~63u) >= nlive) return;
+    if ((il & ~63u) >= nlive) return;
 
-    bool active = i < nlive;
+    bool active = il < nlive;
     const int32_t t = active ? (a.list_in ? a.list_in[i] : static_cast<int32_t>(i)) : 0;
     TrackState s = {0, -1, 0, 0};
     if (active) s = a.state[t];
@@ -724,11 +738,11 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
     const int lane = lane_id;
     const int nsurv = __popcll(live);
     uint32_t base = 0;
-    if (lane == 0 && nsurv) base = atomicAdd(&ctl->count[out_slot], static_cast<uint32_t>(nsurv));
+    if (lane == 0 && nsurv) base = atomicAdd(&ctl->count[out_slot][xcd], static_cast<uint32_t>(nsurv));
     base = __shfl(base, 0);
     if (active) {
         const int rank = __popcll(live & ((1ull << lane) - 1ull));
-        a.list_out[base + rank] = t;
+        a.list_out[xcd * a.cap + base + rank] = t;
         TrackState o;
         o.pos = row | (col << 16);
         o.k = k;
@@ -754,12 +768,13 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_visits(const uint32_t *__re
                                                            long long stride,
                                                            TrackCtl *__restrict__ ctl, int slot,
                                                            uint32_t *__restrict__ hist, int rows,
-                                                           int cols)
+                                                           int cols, uint32_t cap)
 {
     __shared__ uint32_t bins[kBinCells];
     __shared__ uint32_t s_first;
-    const uint32_t nlive = ctl->count[slot];
-    const uint32_t nslots = (nlive + 63u) & ~63u;      // whole waves wrote their slots
+    uint32_t nslots[kXcd];                             // whole waves wrote their slots
+#pragma unroll
+    for (int x = 0; x < kXcd; ++x) nslots[x] = (ctl->count[slot][x] + 63u) & ~63u;
     const uint32_t *v = visits + static_cast<long long>(blockIdx.x) * stride;
     const uint32_t ncell = static_cast<uint32_t>(rows) * cols;
     const int wrows = kBinCells / cols < 1 ? 0 : (kBinCells / cols > rows ? rows : kBinCells / cols);
@@ -767,13 +782,18 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_visits(const uint32_t *__re
     for (int k = threadIdx.x; k < wrows * cols; k += kBinThreads) bins[k] = 0;
     __syncthreads();
     // window origin: the row of the smallest visited cell among a SAMPLE of the
-    // slots (4 per thread, spread over the list).  A full pass would read the
+    // slots (4 per thread: the first 512 of every list).  A full pass would read the
     // step's visits twice; visits below the sampled origin simply count as strays.
     uint32_t mn = 0xFFFFFFFFu;
-    const uint32_t stride4 = nslots / 4 > 0 ? nslots / 4 : 1;
-    for (uint32_t q = 0, j = threadIdx.x; q < 4 && j < nslots; ++q, j += stride4) {
-        const uint32_t c = v[j];
-        mn = c < mn ? c : mn;
+    {
+        const uint32_t x = threadIdx.x % kXcd;
+        uint32_t nx = 0;
+#pragma unroll
+        for (int y = 0; y < kXcd; ++y) nx = (static_cast<uint32_t>(y) == x) ? nslots[y] : nx;
+        for (uint32_t q = 0, j = threadIdx.x / kXcd; q < 4 && j < nx; ++q, j += kBinThreads / kXcd) {
+            const uint32_t c = v[x * cap + j];
+            mn = c < mn ? c : mn;
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -786,10 +806,12 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_visits(const uint32_t *__re
         // the sample saw only idle slots (sparse late launches): look at all of them
         __syncthreads();
         mn = 0xFFFFFFFFu;
-        for (uint32_t j = threadIdx.x; j < nslots; j += kBinThreads) {
-            const uint32_t c = v[j];
-            mn = c < mn ? c : mn;
-        }
+#pragma unroll
+        for (int x = 0; x < kXcd; ++x)
+            for (uint32_t j = threadIdx.x; j < nslots[x]; j += kBinThreads) {
+                const uint32_t c = v[x * cap + j];
+                mn = c < mn ? c : mn;
+            }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             const uint32_t o = __shfl_down(mn, off);
@@ -807,13 +829,15 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_visits(const uint32_t *__re
     const uint32_t base = brow * cols;
     const uint32_t wcells = static_cast<uint32_t>(wrows) * cols;
     uint32_t stray = 0;
-    for (uint32_t j = threadIdx.x; j < nslots; j += kBinThreads) {
-        const uint32_t c = v[j];
-        if (c >= ncell) continue;                      // idle slot
-        const uint32_t off = c - base;
-        if (off < wcells) atomicAdd(&bins[off], 1u);
-        else { atomicAdd(&hist[c], 1u); ++stray; }
-    }
+#pragma unroll
+    for (int x = 0; x < kXcd; ++x)
+        for (uint32_t j = threadIdx.x; j < nslots[x]; j += kBinThreads) {
+            const uint32_t c = v[x * cap + j];
+            if (c >= ncell) continue;                  // idle slot
+            const uint32_t off = c - base;
+            if (off < wcells) atomicAdd(&bins[off], 1u);
+            else { atomicAdd(&hist[c], 1u); ++stray; }
+        }
     // stray count -> host: when the batch no longer moves as a front (tracks
     // trapped or scattered) the host switches back to in-stepper atomics
 #pragma unroll
@@ -837,6 +861,7 @@ struct Workspace {
     size_t sort_temp_bytes;
     uint32_t *visits[2];         // double-buffered: binning of launch L overlaps stepping of L+1
     long long visit_stride;
+    uint32_t cap;                // slots per XCD list
 };
 
 constexpr int kVisitSteps = 256;   // binning mode covers launches of up to this many steps
@@ -854,13 +879,17 @@ static size_t sort_temp_size(int64_t n)
 static size_t workspace_layout(int64_t n, char *base, Workspace *ws)
 {
     size_t off = 0;
+    // kXcd lists of cap slots each; cap is a whole number of blocks
+    const size_t cap = align_up((static_cast<size_t>(n) + kXcd - 1) / kXcd, kBlock);
+    const size_t slots = cap * kXcd;
+    if (ws) ws->cap = static_cast<uint32_t>(cap);
     if (ws) ws->ctl = reinterpret_cast<TrackCtl *>(base + off);
     off = align_up(off + sizeof(TrackCtl), 256);
     if (ws) ws->state = reinterpret_cast<TrackState *>(base + off);
     off = align_up(off + sizeof(TrackState) * static_cast<size_t>(n), 256);
     for (int i = 0; i < 2; ++i) {
         if (ws) ws->list[i] = reinterpret_cast<int32_t *>(base + off);
-        off = align_up(off + sizeof(int32_t) * static_cast<size_t>(n), 256);
+        off = align_up(off + sizeof(int32_t) * slots, 256);
     }
     for (int i = 0; i < 2; ++i) {
         if (ws) ws->keys[i] = reinterpret_cast<unsigned long long *>(base + off);
@@ -869,7 +898,7 @@ static size_t workspace_layout(int64_t n, char *base, Workspace *ws)
     const size_t temp = n > 0 ? sort_temp_size(n) : 0;
     if (ws) { ws->sort_temp = base + off; ws->sort_temp_bytes = temp; }
     off = align_up(off + temp, 256);
-    const long long stride = (n + 63) / 64 * 64;
+    const long long stride = static_cast<long long>(slots);
     // one buffer: binning runs on the launch stream right after its stepper launch
     // (a second buffer would only be needed to overlap it with the next launch)
     if (ws) { ws->visits[0] = ws->visits[1] = reinterpret_cast<uint32_t *>(base + off); ws->visit_stride = stride; }
@@ -1021,7 +1050,7 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
         hipLaunchKernelGGL(k_tracks_init, dim3(blocks), dim3(kBlock), 0, st, start_rc,
                            static_cast<long long>(ntracks), p->rows, p->cols, hist, traj,
                            reinterpret_cast<const long long *>(traj_offsets), lengths, end_rc,
-                           ws.state, ws.ctl, geom, coherent ? 1 : 0);
+                           ws.state, ws.ctl, geom, coherent ? 1 : 0, ws.cap);
         SSRS_HIP_CHECK(hipGetLastError());
     }
 
@@ -1036,6 +1065,7 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
     a.state = ws.state; a.ctl = ws.ctl; a.steps = S;
     a.fast = ((p->flags & SSRS_TRACKS_EXACT_ONLY) == 0 && p->scaling_parameter == 1.0) ? 1 : 0;
     a.coherent = coherent ? 1 : 0;
+    a.cap = ws.cap;
     const bool lean = p->memory_parameter == 1 && traj == nullptr;
     // binning needs the coherent front (a step's visits fall into a few rows)
     // The binning kernel runs on the SAME stream, after its stepper launch.  Running it
@@ -1067,7 +1097,8 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
     for (int i = 0; i < kRing; ++i) SSRS_HIP_CHECK(hipEventCreate(&ev_batch[i]));
     std::vector<hipEvent_t> ev_prof, ev_bin, ev_hist;   // launch starts / ends; binning kernel brackets
     int launch = 0;
-    uint32_t upper = static_cast<uint32_t>(ntracks);   // bound on the live count
+    // bound on the longest XCD list
+    uint32_t upper = static_cast<uint32_t>(ntracks < static_cast<int64_t>(ws.cap) ? ntracks : ws.cap);
     int batches = 0, checked = 0;
     bool finished = false;
     int rc = SSRS_OK;
@@ -1078,7 +1109,7 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
             a.launch = launch;
             a.list_in = (launch == 0 && !coherent) ? nullptr : ws.list[launch & 1];
             a.list_out = ws.list[(launch + 1) & 1];
-            const unsigned blocks = (upper + kBlock - 1) / kBlock;
+            const unsigned blocks = kXcd * ((upper + kBlock - 1) / kBlock);
             const int vb = launch & 1;
             a.visits = nullptr;
             if (binning_on) {
@@ -1112,7 +1143,7 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
                 hipEvent_t b0 = nullptr, b1 = nullptr;
                 if (profile && hipEventCreate(&b0) == hipSuccess) (void)hipEventRecord(b0, st2);
                 hipLaunchKernelGGL(k_bin_visits, dim3(S), dim3(kBinThreads), 0, st2, ws.visits[vb], ws.visit_stride,
-                                   ws.ctl, launch & 3, hist, p->rows, p->cols);
+                                   ws.ctl, launch & 3, hist, p->rows, p->cols, ws.cap);
                 if (profile && b0 && hipEventCreate(&b1) == hipSuccess) {
                     (void)hipEventRecord(b1, st2);
                     ev_hist.push_back(b0);
@@ -1128,10 +1159,10 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
         if (rc != SSRS_OK) break;
         // survivors of this batch = input count of the next launch
         const int slot = batches % kRing;
-        // ring slot = 8 words: [live count, -, steps (2 words), strays (2 words), -, -]
-        if (hipMemcpyAsync(&host_counts[8 * slot], &ws.ctl->count[launch & 3], sizeof(uint32_t),
+        // ring slot = 16 words: [8 list counts, steps (2 words), strays (2 words), -]
+        if (hipMemcpyAsync(&host_counts[16 * slot], ws.ctl->count[launch & 3], kXcd * sizeof(uint32_t),
                            hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipMemcpyAsync(&host_counts[8 * slot + 2], &ws.ctl->steps, 2 * sizeof(unsigned long long),
+            hipMemcpyAsync(&host_counts[16 * slot + 8], &ws.ctl->steps, 2 * sizeof(unsigned long long),
                            hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipEventRecord(ev_batch[slot], st) != hipSuccess) {
             rc = set_error(SSRS_ERR_HIP, "live-count read-back failed");
@@ -1142,9 +1173,10 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
         while (checked < batches - 1) {
             const int cs = checked % kRing;
             if (hipEventSynchronize(ev_batch[cs]) != hipSuccess) { rc = set_error(SSRS_ERR_HIP, "event sync failed"); break; }
-            const uint32_t c = host_counts[8 * cs];
+            uint32_t c = 0;                         // longest list
+            for (int x = 0; x < kXcd; ++x) c = host_counts[16 * cs + x] > c ? host_counts[16 * cs + x] : c;
             unsigned long long tot[2];
-            memcpy(tot, &host_counts[8 * cs + 2], sizeof(tot));
+            memcpy(tot, &host_counts[16 * cs + 8], sizeof(tot));
             ++checked;
             if (c == 0) { finished = true; break; }
             upper = c;   // the live count only shrinks; a stale bound is safe
