@@ -150,13 +150,22 @@ def main():
         pot = torch.from_numpy(ramp_potential(gridsize)).to(dev)
         pot_label = ('LABELLED STAND-IN: linear ramp 1000(1-r/(R-1)) (exact solution for '
                      'uniform conductance); the reference spsolve is infeasible at 3e7 cells')
-    hist = torch.zeros(gridsize, dtype=torch.int32, device=dev)
+    # two histograms: the RCCL reduce of step i runs under the kernels of step i + 1
+    hists = [torch.zeros(gridsize, dtype=torch.int32, device=dev) for _ in range(2 if world > 1 else 1)]
+    pending = [None] * len(hists)
+    step_no = [0]
 
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     acc = dict(raster_ms=0.0, table_ms=0.0, step_kernel_ms=0.0, step_wall_ms=0.0,
                hist_ms=0.0, steps=0, launches=0)
 
     def one_step(timed):
+        slot = step_no[0] % len(hists)
+        step_no[0] += 1
+        hist = hists[slot]
+        if pending[slot] is not None:        # this buffer's previous reduce (two steps ago)
+            pending[slot].wait()
+            pending[slot] = None
         hist.zero_()
         ev[0].record()
         oro, upd = layers.updraft_from_dem(dem, res, 10.0, 270.0, threshold=0.75)
@@ -168,10 +177,12 @@ def main():
                                        hist=hist, steps_per_launch=args.steps_per_launch,
                                        profile=True, exact_only=args.exact_only,
                                        schedule=not args.no_schedule, binning=not args.no_binning)
-        reduce_histogram(hist, dst=0)
+        pending[slot] = reduce_histogram(hist, dst=0, async_op=True)
         ev[3].record()
         if timed:
-            torch.cuda.synchronize()
+            # simulate_tracks returned after its last launch completed, so the
+            # events are final; no device-wide sync (it would wait for the reduce)
+            ev[2].synchronize()
             acc['raster_ms'] += ev[0].elapsed_time(ev[1])
             acc['table_ms'] += ev[1].elapsed_time(ev[2])
             acc['step_kernel_ms'] += out.stats['kernel_ms']
@@ -181,8 +192,15 @@ def main():
             acc['launches'] += out.stats['launches']
         return out
 
+    def drain():
+        for i, w in enumerate(pending):
+            if w is not None:
+                w.wait()
+                pending[i] = None
+
     for _ in range(args.warmup):
         one_step(False)
+    drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -190,9 +208,11 @@ def main():
     last = None
     for _ in range(args.steps):
         last = one_step(True)
+    drain()                                  # every step's reduce is inside the timed region
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    hist = hists[(step_no[0] - 1) % len(hists)]
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -234,7 +254,7 @@ def main():
                          f'threshold 0.75, direction 0, seed 30 (BASELINE.json configs[1])'),
             'tracks_total': n_total,
             'parallelism': f'track-sharded x{world}, replicated rasters'
-                           + (f', {"RCCL" if backend == "nccl" else backend} histogram reduce'
+                           + (f', {"RCCL" if backend == "nccl" else backend} histogram reduce (async, under the next step)'
                               if world > 1 else ''),
             'stepper_path': 'direct 3x3 gathers' if args.direct else 'transition table',
             'potential': pot_label,

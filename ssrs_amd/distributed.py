@@ -19,20 +19,24 @@ def shard_range(ntracks, rank, world_size):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def reduce_histogram(hist, dst=0, group=None, all_ranks=False):
+def reduce_histogram(hist, dst=0, group=None, all_ranks=False, async_op=False):
     """In-place sum of the presence histogram over ranks.
 
     Counts are uint32 stored in an int32 tensor; two's-complement addition makes
     the int32 sum bit-identical to the uint32 sum.  No-op without a process group.
-    """
+
+    async_op=True returns a handle (or None when there is nothing to reduce) whose
+    ``wait()`` orders the current stream after the collective: the reduce of one
+    batch's histogram then runs on RCCL's stream under the next batch's stepper
+    launches (the caller must not touch `hist` before ``wait()``)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return hist
+        return None if async_op else hist
     flat = hist.view(torch.int32).reshape(-1)
     if all_ranks:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
     else:
-        dist.reduce(flat, dst=dst, op=dist.ReduceOp.SUM, group=group)
-    return hist
+        work = dist.reduce(flat, dst=dst, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    return work if async_op else hist
 
 
 def gather_track_summaries(lengths, ends, dst=0, group=None):

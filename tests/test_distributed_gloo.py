@@ -56,6 +56,13 @@ def _worker(rank, world, port, out_dir):
     h2 = torch.from_numpy(res['hist'].view(np.int32).copy())
     reduce_histogram(h2, all_ranks=True)
     np.save(os.path.join(out_dir, f'all_{rank}.npy'), h2.numpy())
+    # the pipelined form bench.py uses: two buffers, reduce i in flight while i + 1 is filled
+    bufs = [torch.from_numpy(res['hist'].view(np.int32).copy()) for _ in range(2)]
+    works = [reduce_histogram(b, all_ranks=True, async_op=True) for b in bufs]
+    for w in works:
+        assert w is not None
+        w.wait()
+    assert all(torch.equal(b, h2) for b in bufs)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -80,3 +87,4 @@ def test_reduce_is_noop_without_process_group():
     from ssrs_amd.distributed import reduce_histogram
     h = torch.arange(12, dtype=torch.int32).reshape(3, 4)
     assert reduce_histogram(h) is h
+    assert reduce_histogram(h, async_op=True) is None
