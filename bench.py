@@ -51,6 +51,7 @@ def parse():
     ap.add_argument('--no-binning', action='store_true', help='per-step global atomics for the histogram')
     ap.add_argument('--no-schedule', action='store_true', help='disable the coherent schedule')
     ap.add_argument('--exact-only', action='store_true', help='disable the fast decision path')
+    ap.add_argument('--f64-table', action='store_true', help='8 x f64 transition table instead of the f32 ring table')
     return ap.parse_args()
 
 
@@ -170,7 +171,7 @@ def main():
         ev[0].record()
         oro, upd = layers.updraft_from_dem(dem, res, 10.0, 270.0, threshold=0.75)
         ev[1].record()
-        table = None if args.direct else movmodel.build_transition_table(upd, pot)
+        table = None if args.direct else movmodel.build_transition_table(upd, pot, ring=not (args.f64_table or args.exact_only))
         ev[2].record()
         out = movmodel.simulate_tracks(0.0, starts, gridsize, 1, 1.0, upd, pot, seed=seed,
                                        track_id_base=lo, table=table, use_table=not args.direct,
@@ -256,7 +257,9 @@ def main():
             'parallelism': f'track-sharded x{world}, replicated rasters'
                            + (f', {"RCCL" if backend == "nccl" else backend} histogram reduce (async, under the next step)'
                               if world > 1 else ''),
-            'stepper_path': 'direct 3x3 gathers' if args.direct else 'transition table',
+            'stepper_path': ('direct 3x3 gathers' if args.direct else
+                             ('f64 transition table' if (args.f64_table or args.exact_only)
+                              else 'f32 ring table, exact fallback on the raw windows')),
             'potential': pot_label,
         },
         'steps_per_s': total_steps_all / elapsed,

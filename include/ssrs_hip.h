@@ -141,6 +141,11 @@ typedef struct SsrsTrackParams {
                                     (A/B switch for the coherent schedule) */
 #define SSRS_TRACKS_NO_BINNING 8  /* histogram by per-step global atomics instead of the
                                     visit buffer + LDS binning kernel (A/B switch) */
+#define SSRS_TRACKS_RING_TABLE 16 /* `table` is the f32 ring table of
+                                    ssrs_transition_ring_build (one 12-byte gather per step);
+                                    needs updraft (+ potential if the table was built with it)
+                                    for the exact decision of near-ties, memory_parameter 1,
+                                    scaling_parameter 1, traj NULL, even steps_per_launch */
 #define SSRS_TRACKS_EXACT_ONLY 2 /* disable the guarded division-free decision
                                    (A/B switch; results are identical) */
 
@@ -165,6 +170,15 @@ int ssrs_track_params_init(SsrsTrackParams *p, int rows, int cols,
  * potential may be NULL (updraft-only weights).  table: rows*cols*8 f64. */
 int ssrs_transition_table_build(const double *updraft, const float *potential,
                                 double *table, int rows, int cols, void *stream);
+
+/* The same weights for the three-candidate stepper (SSRS_TRACKS_RING_TABLE): after
+ * a move only the three cells within +-45 deg are admissible (movmodel.py:185-202),
+ * and in clockwise ring order N, NE, E, SE, S, SW, W, NW they are consecutive.  Per
+ * cell 10 f32 = the ring-ordered weights rounded to f32, stored as ring 7, 0, 1, ...,
+ * 7, 0 (40 B).  ring: ssrs_transition_ring_bytes(rows, cols) bytes, 8-byte aligned. */
+size_t ssrs_transition_ring_bytes(int rows, int cols);
+int ssrs_transition_ring_build(const double *updraft, const float *potential, float *ring,
+                               int rows, int cols, void *stream);
 
 /* Bytes of device scratch ssrs_tracks_simulate needs for `ntracks`. */
 size_t ssrs_tracks_workspace_bytes(int64_t ntracks);

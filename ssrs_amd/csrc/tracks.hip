@@ -104,6 +104,76 @@ __device__ __forceinline__ uint32_t candidates_of(uint32_t d)
     return static_cast<uint32_t>(v) & 0x1FFu;
 }
 
+// Ring order of the eight neighbours (clockwise from north): with it the three
+// cells admissible after a move are CONSECUTIVE, so a table stored in ring order
+// (two entries repeated at the end) yields them with one 12-byte load.
+constexpr int kRingK[8] = {7, 8, 5, 2, 1, 0, 3, 6};           // ring position -> k
+constexpr int ring_of_k(int k)
+{
+    for (int c = 0; c < 8; ++c)
+        if (kRingK[c] == k) return c;
+    return 8;                                                 // centre: "no move yet"
+}
+constexpr bool ring_matches_restrictions()
+{
+    for (int c = 0; c < 8; ++c) {
+        const uint32_t m = (1u << kRingK[(c + 7) % 8]) | (1u << kRingK[c]) | (1u << kRingK[(c + 1) % 8]);
+        if (m != restriction(kRingK[c])) return false;
+    }
+    return true;
+}
+static_assert(ring_matches_restrictions(), "restriction(d) = ring neighbours of d");
+// order[c]: for the triple (ring c-1, c, c+1) as loaded (x0, x1, x2), which x is
+// the 1st / 2nd / 3rd in ascending k (the order np.cumsum runs in); 2 bits each
+constexpr uint32_t ring_order(int c)
+{
+    const int ks[3] = {kRingK[(c + 7) % 8], kRingK[c], kRingK[(c + 1) % 8]};
+    uint32_t v = 0;
+    int n = 0;
+    for (int k = 0; k < 9; ++k)
+        for (int j = 0; j < 3; ++j)
+            if (ks[j] == k) v |= static_cast<uint32_t>(j) << (2 * n++);
+    return v;
+}
+constexpr uint64_t pack_ring_orders()
+{
+    uint64_t v = 0;
+    for (int c = 0; c < 8; ++c) v |= static_cast<uint64_t>(ring_order(c)) << (6 * c);
+    return v;
+}
+constexpr uint64_t kRingOrder = pack_ring_orders();
+constexpr uint32_t kOrdId = 0u | (1u << 2) | (2u << 4), kOrdRot = 2u | (0u << 2) | (1u << 4),
+                   kOrdRev = 2u | (1u << 2) | (0u << 4), kOrdSwp = 1u | (0u << 2) | (2u << 4);
+static_assert(ring_order(0) == kOrdId && ring_order(6) == kOrdId && ring_order(7) == kOrdId, "x0 x1 x2");
+static_assert(ring_order(1) == kOrdRot, "after NE: x2 x0 x1");
+static_assert(ring_order(2) == kOrdRev && ring_order(3) == kOrdRev && ring_order(4) == kOrdRev, "x2 x1 x0");
+static_assert(ring_order(5) == kOrdSwp, "after SW: x1 x0 x2");
+static_assert(ring_order(0) == (0u | (1u << 2) | (2u << 4)), "after N: NW, N, NE are k = 6, 7, 8");
+static_assert(ring_order(2) == (2u | (1u << 2) | (0u << 4)), "after E: NE, E, SE are k = 8, 5, 2");
+constexpr uint32_t pack_ring_deltas(bool rows)
+{
+    uint32_t v = 0;
+    for (int c = 0; c < 8; ++c)
+        v |= static_cast<uint32_t>((rows ? dr_of(kRingK[c]) : dc_of(kRingK[c])) + 1) << (2 * c);
+    return v;
+}
+constexpr uint32_t kRingDr = pack_ring_deltas(true), kRingDc = pack_ring_deltas(false);
+constexpr uint64_t pack_ring_of_k()
+{
+    uint64_t v = 0;
+    for (int k = 0; k < 9; ++k) v |= static_cast<uint64_t>(ring_of_k(k)) << (4 * k);
+    return v;
+}
+constexpr uint64_t kRingOfK = pack_ring_of_k();
+constexpr uint64_t pack_k_of_ring()
+{
+    uint64_t v = 4ull << 32;                                  // ring 8 -> k = 4
+    for (int c = 0; c < 8; ++c) v |= static_cast<uint64_t>(kRingK[c]) << (4 * c);
+    return v;
+}
+constexpr uint64_t kKOfRing = pack_k_of_ring();
+constexpr int kRingFloats = 10;                               // ring 7, 0, 1, ..., 7, 0 per cell
+
 // ------------------------------------------------------------------- uniform
 // rocRAND Philox4x32-10: key = seed, counter = (blk, track); one 4-word block
 // serves two steps.  The engine is built and dropped in registers (stateless).
@@ -266,6 +336,25 @@ __device__ __forceinline__ int choose_three_fast(double wa, double wb, double wc
     return near ? -1 : sel;
 }
 
+// Ring-table form: the three weights are the f64 table values rounded to f32
+// (relative error <= 2^-24 each, or < 2^-126 absolute when tiny), so the running
+// sums and u * total are within 2^-23 * total of the f64 quantities the exact
+// sequence compares: outside a band of 2^-21 * total both decide alike.  Totals
+// that are tiny, infinite (f32 overflow) or NaN (poisoned row) go to the exact path.
+__device__ __forceinline__ int choose_three_ring(float fa, float fb, float fc, double u)
+{
+    const double ca = static_cast<double>(fa);
+    const double cb = ca + static_cast<double>(fb);
+    const double acc = cb + static_cast<double>(fc);
+    const double ut = u * acc;
+    const double band = acc * 0x1p-21;
+    const double da = ca - ut, db = cb - ut;
+    const int sel = da > 0.0 ? 0 : (db > 0.0 ? 1 : 2);
+    const double closest = fmin(fabs(da), fabs(db));
+    const bool near = !(acc > 0x1p-90) || !(closest > band);
+    return near ? -1 : sel;
+}
+
 // Raw 3x3 move weights of movmodel.py:292-306 at an interior cell.
 template <bool HAS_POT>
 __device__ __forceinline__ void window_weights(const double *__restrict__ updraft,
@@ -307,9 +396,12 @@ __device__ __forceinline__ int xcd_band(int b, int n)
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
 }
 
+// RING: the same weights rounded to f32 and stored in ring order, 10 floats per
+// cell (ring 7, 0, 1, ..., 7, 0), for the three-candidate stepper (k_step_lean).
+template <bool RING>
 __global__ __launch_bounds__(kBlock) void k_transition_table(
     const double *__restrict__ updraft, const float *__restrict__ potential,
-    double *__restrict__ table, int rows, int cols, int tiles_x, int ntiles)
+    void *__restrict__ table_out, int rows, int cols, int tiles_x, int ntiles)
 {
     // LDS tiles (+1-cell halo) of the clipped updraft reciprocals and of the
     // potential: every cell's 1/max(u, 1e-6) is needed by its 9 neighbours, so it
@@ -362,15 +454,27 @@ __global__ __launch_bounds__(kBlock) void k_transition_table(
         bool has_nan = false;
 #pragma unroll
         for (int j = 0; j < 9; ++j) has_nan |= (w[j] != w[j]);
-        double2 *dst = reinterpret_cast<double2 *>(table + i * 8);
-        double o[8];
+        if (RING) {
+            float f[kRingFloats];
 #pragma unroll
-        for (int j = 0, k = 0; j < 9; ++j) {
-            if (j == 4) continue;
-            o[k++] = has_nan ? __builtin_nan("") : (w[j] > 0.0 ? w[j] : 0.0);
+            for (int j = 0; j < kRingFloats; ++j) {
+                const double v = w[kRingK[(j + 7) % 8]];
+                f[j] = static_cast<float>(has_nan ? __builtin_nan("") : (v > 0.0 ? v : 0.0));
+            }
+            float2 *dst = reinterpret_cast<float2 *>(static_cast<float *>(table_out) + i * kRingFloats);
+#pragma unroll
+            for (int k = 0; k < kRingFloats / 2; ++k) dst[k] = make_float2(f[2 * k], f[2 * k + 1]);
+        } else {
+            double2 *dst = reinterpret_cast<double2 *>(static_cast<double *>(table_out) + i * 8);
+            double o[8];
+#pragma unroll
+            for (int j = 0, k = 0; j < 9; ++j) {
+                if (j == 4) continue;
+                o[k++] = has_nan ? __builtin_nan("") : (w[j] > 0.0 ? w[j] : 0.0);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dst[k] = make_double2(o[2 * k], o[2 * k + 1]);
         }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) dst[k] = make_double2(o[2 * k], o[2 * k + 1]);
     }
 }
 
@@ -757,6 +861,241 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
     if (lane == 0 && m) atomicAdd(&ctl->steps, m);
 }
 
+// ---------------------------------------------------------------- lean stepper
+// The production configuration (table, memory_parameter 1, nu = 1, no trajectory
+// output, even S) written flat: a step is bound by its chain of dependent
+// instructions, and about 100 of the generic kernel's ~230 per step were exec-mask
+// bookkeeping of nested divergent branches.  Here
+//  * the Philox block is evaluated on even iterations by every lane (release
+//    delays are even and S is even, so the parity of a track's step count equals
+//    the parity of the iteration for every lane: no per-lane branch),
+//  * the loop head of the next step (done / nudged cell) is a pure function of
+//    (row, col, k) and is recomputed unconditionally by all lanes,
+//  * the move itself is predicated with selects,
+//  * lengths / end cells of tracks that finish are written after the loop (a
+//    finished lane's row, col, k are frozen),
+// which leaves two rare wave-level branches in the loop: the exact decision
+// (first step of a track, near-ties, poisoned rows) and the burn-in nudge.
+// Results are identical to k_step_tracks<MODE_TABLE, true> (same tests).
+constexpr uint32_t pack_slot_deltas(bool rows)
+{
+    uint32_t v = 0;
+    for (int j = 0; j < 8; ++j) {
+        const int k = j < 4 ? j : j + 1;
+        v |= static_cast<uint32_t>((rows ? dr_of(k) : dc_of(k)) + 1) << (2 * j);
+    }
+    return v;
+}
+constexpr uint32_t kSlotDr = pack_slot_deltas(true), kSlotDc = pack_slot_deltas(false);
+
+struct __attribute__((packed, aligned(4))) RingTriple { float x0, x1, x2; };
+
+// RING: a.table is the f32 ring table (ssrs_transition_ring_build): ONE 12-byte
+// gather per step instead of three 8-byte ones (a 64-lane gather costs the CU's
+// address unit ~64 cycles whatever its width: with 6 waves per CU the three
+// gathers were half of a step's time); near-ties are decided by the exact
+// sequence on the raw 3x3 windows of updraft / potential.
+template <bool RING>
+__global__ __launch_bounds__(kBlock) void k_step_lean(const StepArgs a)
+{
+    TrackCtl *ctl = a.ctl;
+    const int in_slot = a.launch & 3, out_slot = (a.launch + 1) & 3;
+    const uint32_t xcd = blockIdx.x % kXcd;
+    const uint32_t nlive = ctl->count[in_slot][xcd];
+    const uint32_t il = (blockIdx.x / kXcd) * kBlock + threadIdx.x;
+    const uint32_t i = xcd * a.cap + il;
+    if (blockIdx.x == 0 && threadIdx.x < kXcd) ctl->count[(a.launch + 2) & 3][threadIdx.x] = 0;
+    if ((il & ~63u) >= nlive) return;
+
+    bool active = il < nlive;
+    const int32_t t = active ? (a.list_in ? a.list_in[i] : static_cast<int32_t>(i)) : 0;
+    TrackState s = {0, -1, 0, 0};
+    if (active) s = a.state[t];
+    active = active && s.k >= 0;
+    const bool was_active = active;
+    int row = s.pos & 0xFFFF, col = (s.pos >> 16) & 0xFFFF;
+    int k = s.k;
+    const int max_k = static_cast<int>(a.max_k);
+    uint32_t dirs = s.dirs;
+    // RING: ring position of the last move (8 = none yet) instead of its k
+    uint32_t rc = static_cast<uint32_t>(kRingOfK >> (4 * (dirs & 0xFu))) & 0xFu;
+    (void)rc;
+    const long long rel64 = (a.coherent ? static_cast<long long>(s.aux >> 9) : 0) -
+                            static_cast<long long>(a.launch) * a.steps;
+    const int release = rel64 > 0x7fffffffLL ? 0x7fffffff : (rel64 < 0 ? 0 : static_cast<int>(rel64));
+    const unsigned long long track = a.track_base + static_cast<unsigned long long>(t);
+    uint32_t pend_a = 0, pend_b = 0, moved = 0;
+    const uint32_t ucols = static_cast<uint32_t>(a.cols);
+    const uint32_t in_rows = static_cast<uint32_t>(a.rows - 2), in_cols = static_cast<uint32_t>(a.cols - 2);
+
+    bool done;
+    int er, ec;
+    // movmodel.py:285-291 for (row, col, k); rows, cols <= 32767
+    auto loop_head = [&]() {
+        const bool interior = static_cast<uint32_t>(row - 1) < in_rows && static_cast<uint32_t>(col - 1) < in_cols;
+        done = !(k < max_k) || (k > a.burnin && !interior);
+        er = row;
+        ec = col;
+        if (__any(k <= a.burnin)) {                       // first burnin steps of a track only
+            if (k <= a.burnin) {
+                if (er <= 1) er += 2; else if (er >= a.rows - 2) er -= 2;
+                if (ec <= 0) ec += 2; else if (ec >= a.cols - 2) ec -= 2;
+            }
+        }
+    };
+    double ta = 0.0, tb = 0.0, tc = 0.0;
+    uint32_t cand = 0;
+    RingTriple x = {0.f, 0.f, 0.f};
+    (void)ta; (void)tb; (void)tc; (void)cand; (void)x;
+    auto fetch_entry = [&]() {
+        const uint32_t cell = __umul24(static_cast<uint32_t>(er), ucols) + static_cast<uint32_t>(ec);
+        if (RING) {
+            // triple (ring rc-1, rc, rc+1) = floats rc .. rc+2 of the cell's record
+            const float *src = reinterpret_cast<const float *>(a.table) +
+                               static_cast<size_t>(cell) * kRingFloats + (rc & 7u);
+            x = *reinterpret_cast<const RingTriple *>(src);
+        } else {
+            cand = candidates_of(dirs & 0xFu);
+            const double *src = a.table + static_cast<size_t>(cell) * 8;
+            ta = src[cand & 7u];
+            tb = src[(cand >> 3) & 7u];
+            tc = src[cand >> 6];
+        }
+    };
+    loop_head();
+    fetch_entry();
+
+    int last_it = -1;
+    auto one_step = [&](const int it, const bool even) {
+        const bool go = active && it >= release;
+        const bool st = go && !done;
+        active = active && !(go && done);                 // finished: row, col, k stay frozen
+        // ---- uniform for step k (parity of k == parity of it, see above)
+        uint32_t w0, w1;
+        if (even) {
+            const uint4 w4 = philox_block(a.seed, track, static_cast<unsigned long long>(static_cast<uint32_t>(k) >> 1));
+            w0 = w4.x; w1 = w4.y; pend_a = w4.z; pend_b = w4.w;
+        } else {
+            w0 = pend_a; w1 = pend_b;
+        }
+        const double u = words_to_uniform(w0, w1);
+        // ---- decision among the three admissible cells
+        int nrow, ncol;
+        if (RING) {
+            const uint32_t ord = static_cast<uint32_t>(kRingOrder >> (6 * (rc & 7u))) & 63u;
+            // (x0, x1, x2) -> ascending k.  Only four orders occur (static_asserts below);
+            // written as two-way selects on the bit patterns so that they stay v_cndmask
+            // (a three-way pick became branches that dragged the vmcnt wait above Philox)
+            const uint32_t b0 = __float_as_uint(x.x0), b1 = __float_as_uint(x.x1), b2 = __float_as_uint(x.x2);
+            const bool rot = ord == ring_order(1), rev = ord == ring_order(2), swp = ord == ring_order(5);
+            const uint32_t ba = (rot || rev) ? b2 : (swp ? b1 : b0);
+            const uint32_t bb = (rot || swp) ? b0 : b1;
+            const uint32_t bc = rev ? b0 : (rot ? b1 : b2);
+            const int sel = choose_three_ring(__uint_as_float(ba), __uint_as_float(bb), __uint_as_float(bc), u);
+            // ring position of the chosen cell: rc - 1 + (which x it was)
+            uint32_t nc = (rc + 7u + ((ord >> (2 * (sel < 0 ? 0 : sel))) & 3u)) & 7u;
+            const bool slow = st && (sel < 0 || rc == 8u);
+            if (__builtin_expect(__any(slow), 0)) {
+                if (slow) {
+                    // first step of a track (8 admissible cells), near-ties, poisoned rows:
+                    // the reference's exact sequence on the raw windows (movmodel.py:292-312)
+                    double w[9];
+                    if (a.potential) window_weights<true>(a.updraft, a.potential, a.cols, er, ec, w);
+                    else window_weights<false>(a.updraft, a.potential, a.cols, er, ec, w);
+                    double pr[9];
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) pr[j] = a.prior[j];
+                    const uint32_t last = static_cast<uint32_t>(kKOfRing >> (4 * rc)) & 0xFu;
+                    const int idx = choose_move(w, pr, 1.0, restriction_of(last), u, false);
+                    nc = static_cast<uint32_t>(kRingOfK >> (4 * idx)) & 0xFu;
+                }
+            }
+            nrow = er + static_cast<int>((kRingDr >> (2 * nc)) & 3u) - 1;
+            ncol = ec + static_cast<int>((kRingDc >> (2 * nc)) & 3u) - 1;
+            rc = st ? nc : rc;
+        } else {
+            const uint32_t last = dirs & 0xFu;
+            const int sel = choose_three_fast(ta, tb, tc, u);
+            const uint32_t slot = (cand >> (3 * (sel < 0 ? 0 : sel))) & 7u;
+            int idx = static_cast<int>(slot + (slot >= 4u ? 1u : 0u));
+            const bool slow = st && (sel < 0 || last == 4u);
+            if (__builtin_expect(__any(slow), 0)) {
+                if (slow) {
+                    // first step of a track (8 admissible cells), near-ties, poisoned rows:
+                    // the reference's exact sequence on the full row (movmodel.py:220-244)
+                    const double *src = a.table + static_cast<size_t>(__umul24(static_cast<uint32_t>(er), ucols) +
+                                                                      static_cast<uint32_t>(ec)) * 8;
+                    double o[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = __builtin_nontemporal_load(src + j);
+                    const double w[9] = {o[0], o[1], o[2], o[3], 0.0, o[4], o[5], o[6], o[7]};
+                    double pr[9];
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) pr[j] = a.prior[j];
+                    idx = choose_move(w, pr, 1.0, restriction_of(last), u, false);
+                }
+            }
+            const int j8 = idx - (idx > 4 ? 1 : 0);
+            nrow = er + static_cast<int>((kSlotDr >> (2 * j8)) & 3u) - 1;
+            ncol = ec + static_cast<int>((kSlotDc >> (2 * j8)) & 3u) - 1;
+            dirs = st ? ((dirs << 4) | static_cast<uint32_t>(idx)) : dirs;
+        }
+        // ---- move (predicated), head of the next step (unconditional: a pure
+        // function of row, col, k, so idle lanes recompute what they had)
+        row = st ? nrow : row;
+        col = st ? ncol : col;
+        k += st ? 1 : 0;
+        moved += st ? 1u : 0u;
+        loop_head();
+        fetch_entry();
+        // ---- presence histogram (see k_step_tracks)
+        const uint32_t cell = __umul24(static_cast<uint32_t>(row), ucols) + static_cast<uint32_t>(col);
+        if (a.visits) {
+            a.visits[static_cast<long long>(it) * a.visit_stride + i] = st ? cell : 0xFFFFFFFFu;
+        } else if (a.hist) {
+            atomicAdd(&a.hist[cell], st ? 1u : 0u);
+        }
+        last_it = it;
+    };
+    for (int it = 0; it < a.steps; it += 2) {             // a.steps is even (host)
+        if (!__any(active)) break;
+        one_step(it, true);
+        one_step(it + 1, false);
+    }
+    if (a.visits)
+        for (int it = last_it + 1; it < a.steps; ++it)
+            a.visits[static_cast<long long>(it) * a.visit_stride + i] = 0xFFFFFFFFu;
+
+    // tracks that finished in this launch
+    if (was_active && !active) {
+        if (a.lengths) a.lengths[t] = static_cast<int32_t>(k + 1);
+        if (a.end_rc)
+            reinterpret_cast<uint32_t *>(a.end_rc)[t] =
+                static_cast<uint32_t>(row & 0xFFFF) | (static_cast<uint32_t>(col) << 16);
+    }
+    // survivors -> next launch's list of this XCD
+    const unsigned long long live = __ballot(active);
+    const int lane = threadIdx.x & 63;
+    const int nsurv = __popcll(live);
+    uint32_t base = 0;
+    if (lane == 0 && nsurv) base = atomicAdd(&ctl->count[out_slot][xcd], static_cast<uint32_t>(nsurv));
+    base = __shfl(base, 0);
+    if (active) {
+        const int rank = __popcll(live & ((1ull << lane) - 1ull));
+        a.list_out[xcd * a.cap + base + rank] = t;
+        TrackState o;
+        o.pos = row | (col << 16);
+        o.k = k;
+        o.dirs = RING ? (static_cast<uint32_t>(kKOfRing >> (4 * rc)) & 0xFu) : dirs;
+        o.aux = s.aux;
+        a.state[t] = o;
+    }
+    unsigned long long m = moved;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m += __shfl_down(m, off);
+    if (lane == 0 && m) atomicAdd(&ctl->steps, m);
+}
+
 // K3 binning: one block per step of the launch.  The coherent schedule keeps the
 // whole batch on a front a few raster rows deep, so one step's visits fall into
 // a window of a few rows: counted with LDS atomics, flushed with contiguous
@@ -957,8 +1296,29 @@ extern "C" int ssrs_transition_table_build(const double *updraft, const float *p
     SSRS_REQUIRE((reinterpret_cast<uintptr_t>(table) & 63u) == 0,
                  "ssrs_transition_table_build: table must be 64-byte aligned");
     const int tx = (cols + kTabW - 1) / kTabW, ty = (rows + kTabH - 1) / kTabH, nt = tx * ty;
-    hipLaunchKernelGGL(k_transition_table, dim3(static_cast<unsigned>(nt)), dim3(kBlock), 0,
-                       as_stream(stream), updraft, potential, table, rows, cols, tx, nt);
+    hipLaunchKernelGGL(k_transition_table<false>, dim3(static_cast<unsigned>(nt)), dim3(kBlock), 0,
+                       as_stream(stream), updraft, potential, static_cast<void *>(table), rows, cols, tx, nt);
+    SSRS_HIP_CHECK(hipGetLastError());
+    return SSRS_OK;
+}
+
+extern "C" size_t ssrs_transition_ring_bytes(int rows, int cols)
+{
+    if (rows <= 0 || cols <= 0) return 0;
+    // + 8 bytes: the 12-byte load of the last cell's last triple stays inside the buffer
+    return static_cast<size_t>(rows) * static_cast<size_t>(cols) * kRingFloats * sizeof(float) + 8;
+}
+
+extern "C" int ssrs_transition_ring_build(const double *updraft, const float *potential,
+                                          float *ring, int rows, int cols, void *stream)
+{
+    SSRS_REQUIRE(updraft && ring, "ssrs_transition_ring_build: updraft/ring is NULL");
+    SSRS_REQUIRE(rows >= 3 && cols >= 3, "ssrs_transition_ring_build: need rows, cols >= 3");
+    SSRS_REQUIRE((reinterpret_cast<uintptr_t>(ring) & 7u) == 0,
+                 "ssrs_transition_ring_build: ring must be 8-byte aligned");
+    const int tx = (cols + kTabW - 1) / kTabW, ty = (rows + kTabH - 1) / kTabH, nt = tx * ty;
+    hipLaunchKernelGGL(k_transition_table<true>, dim3(static_cast<unsigned>(nt)), dim3(kBlock), 0,
+                       as_stream(stream), updraft, potential, static_cast<void *>(ring), rows, cols, tx, nt);
     SSRS_HIP_CHECK(hipGetLastError());
     return SSRS_OK;
 }
@@ -1067,6 +1427,11 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
     a.coherent = coherent ? 1 : 0;
     a.cap = ws.cap;
     const bool lean = p->memory_parameter == 1 && traj == nullptr;
+    const bool ring = (p->flags & SSRS_TRACKS_RING_TABLE) != 0;
+    if (ring)
+        SSRS_REQUIRE(table && updraft && lean && a.fast && (S & 1) == 0,
+                     "ssrs_tracks_simulate: SSRS_TRACKS_RING_TABLE needs table + updraft, memory_parameter 1, "
+                     "scaling_parameter 1, no trajectory output, no EXACT_ONLY and an even steps_per_launch");
     // binning needs the coherent front (a step's visits fall into a few rows)
     // The binning kernel runs on the SAME stream, after its stepper launch.  Running it
     // on a side stream to overlap the next launch was measured and rejected: its
@@ -1122,7 +1487,9 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
             }
             switch (mode) {
             case MODE_TABLE:
-                if (lean) hipLaunchKernelGGL((k_step_tracks<MODE_TABLE, true>), dim3(blocks), dim3(kBlock), 0, st, a);
+                if (ring) hipLaunchKernelGGL(k_step_lean<true>, dim3(blocks), dim3(kBlock), 0, st, a);
+                else if (lean && a.fast && (S & 1) == 0) hipLaunchKernelGGL(k_step_lean<false>, dim3(blocks), dim3(kBlock), 0, st, a);
+                else if (lean) hipLaunchKernelGGL((k_step_tracks<MODE_TABLE, true>), dim3(blocks), dim3(kBlock), 0, st, a);
                 else hipLaunchKernelGGL((k_step_tracks<MODE_TABLE, false>), dim3(blocks), dim3(kBlock), 0, st, a);
                 break;
             case MODE_FLUIDFLOW: hipLaunchKernelGGL(k_step_tracks<MODE_FLUIDFLOW>, dim3(blocks), dim3(kBlock), 0, st, a); break;

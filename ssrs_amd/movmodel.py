@@ -76,7 +76,7 @@ def get_directional_probs(theta):
 
 def make_track_params(grid_shape, move_dirn, memory_parameter=1, scaling_parameter=1.,
                       steps_per_launch=0, profile=False, exact_only=False, schedule=True,
-                      binning=True):
+                      binning=True, ring=False):
     rows, cols = int(grid_shape[0]), int(grid_shape[1])
     p = nat.SsrsTrackParams()
     nat.check(nat.lib().ssrs_track_params_init(C.byref(p), rows, cols, int(memory_parameter),
@@ -88,21 +88,36 @@ def make_track_params(grid_shape, move_dirn, memory_parameter=1, scaling_paramet
     p.flags = (nat.SSRS_TRACKS_PROFILE if profile else 0) | \
         (nat.SSRS_TRACKS_EXACT_ONLY if exact_only else 0) | \
         (0 if schedule else nat.SSRS_TRACKS_NO_SCHEDULE) | \
-        (0 if binning else nat.SSRS_TRACKS_NO_BINNING)
+        (0 if binning else nat.SSRS_TRACKS_NO_BINNING) | \
+        (nat.SSRS_TRACKS_RING_TABLE if ring else 0)
     return p
 
 
-def build_transition_table(updraft, potential):
-    """Per-cell move weights (8 x f64 per cell) for the table stepper."""
+def build_transition_table(updraft, potential, ring=False):
+    """Per-cell move weights for the table stepper: 8 x f64 per cell (any
+    memory_parameter), or with ring=True the f32 ring table (10 x f32 per cell, a
+    1-D float32 tensor) of the three-candidate stepper (memory_parameter 1)."""
     upd = to_dev(updraft, torch.float64)
     pot = to_dev(potential, torch.float32)
     rows, cols = int(upd.shape[0]), int(upd.shape[1])
     if pot is not None and tuple(pot.shape) != (rows, cols):
         raise ValueError('updraft and potential shapes differ')
+    if ring:
+        nbytes = nat.lib().ssrs_transition_ring_bytes(rows, cols)
+        table = torch.empty(nbytes // 4, dtype=torch.float32, device=upd.device)
+        nat.check(nat.lib().ssrs_transition_ring_build(
+            nat.ptr(upd), nat.ptr(pot), nat.ptr(table), rows, cols, stream_ptr()))
+        return table
     table = torch.empty((rows, cols, 8), dtype=torch.float64, device=upd.device)
     nat.check(nat.lib().ssrs_transition_table_build(
         nat.ptr(upd), nat.ptr(pot), nat.ptr(table), rows, cols, stream_ptr()))
     return table
+
+
+def ring_table_applies(memory_parameter, scaling_parameter, want_tracks, exact_only, steps_per_launch):
+    """The f32 ring table serves the reference's default movement model only."""
+    return (int(memory_parameter) == 1 and float(scaling_parameter) == 1.0 and not want_tracks
+            and not exact_only and int(steps_per_launch) % 2 == 0)
 
 
 class TrackBatch:
@@ -129,15 +144,17 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
                     scaling_parameter=1., updraft_field=None, potential_field=None, *,
                     seed=0, track_id_base=0, table=None, use_table=None, hist=None,
                     want_hist=True, want_tracks=False, steps_per_launch=0, profile=False,
-                    exact_only=False, schedule=True, binning=True):
+                    exact_only=False, schedule=True, binning=True, ring=None):
     """generate_simulated_tracks for a whole batch (movmodel.py:264-318 under
     simulator.py:360-369) + presence histogram (movmodel.py:410-419).
 
     starts: int (n, 2) [row, col].  updraft_field f64 / potential_field f32
     rasters (numpy or CUDA tensors); both None = 'drw'.  `table` (from
     build_transition_table) or use_table=True selects the one-fetch-per-step
-    path; default: table when it pays (many steps per cell).
-    `hist` (int32/uint32 CUDA tensor) is accumulated into when given.
+    path; default: table when it pays (many steps per cell).  A float32
+    `table` is the ring table (build_transition_table(..., ring=True)); when the
+    table is built here, ring=None picks it whenever it applies (memory 1, nu 1,
+    no trajectories).  `hist` (int32/uint32 CUDA tensor) is accumulated into when given.
     """
     rows, cols = int(grid_shape[0]), int(grid_shape[1])
     dev = device()
@@ -157,9 +174,17 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
             # takes more steps than that (>= ~rows steps per track)
             use_table = n * rows >= 4 * rows * cols
         if use_table:
-            table = build_transition_table(upd, pot)
+            if ring is None:
+                ring = ring_table_applies(memory_parameter, scaling_parameter, want_tracks,
+                                          exact_only, steps_per_launch)
+            table = build_transition_table(upd, pot, ring=bool(ring))
+    is_ring = table is not None and table.dtype == torch.float32
+    if is_ring and not ring_table_applies(memory_parameter, scaling_parameter, want_tracks,
+                                          exact_only, steps_per_launch):
+        raise ValueError('the ring table needs memory_parameter 1, scaling_parameter 1, no '
+                         'trajectory output, exact_only=False and an even steps_per_launch')
     p = make_track_params((rows, cols), move_dirn, memory_parameter, scaling_parameter,
-                          steps_per_launch, profile, exact_only, schedule, binning)
+                          steps_per_launch, profile, exact_only, schedule, binning, ring=is_ring)
     if hist is None and want_hist:
         hist = torch.zeros((rows, cols), dtype=torch.int32, device=dev)
     lengths = torch.empty(n, dtype=torch.int32, device=dev)

@@ -346,3 +346,99 @@ def test_binned_histogram_path_with_trajectories(gpu):
         alt = movmodel.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=11,
                                        track_id_base=5, **kw)
         assert torch.equal(alt.hist, got.hist) and torch.equal(alt.lengths, got.lengths)
+
+
+# ------------------------------------------------------------------ ring table
+# The f32 ring table (one 12-byte gather per step) must give the reference's
+# tracks bit for bit: its guarded decision falls back to the exact sequence on
+# the raw windows whenever f32 rounding could matter.
+
+def _no_traj_result(res):
+    return (res.lengths.cpu().numpy(), res.ends.cpu().numpy(),
+            res.hist.cpu().numpy().view(np.uint32))
+
+
+@pytest.mark.parametrize('ring', [False, True])
+def test_ring_table_c1_golden(gpu, golden, ring):
+    from ssrs_amd import movmodel, layers
+    g = golden('g8_c1.npz')
+    upd = layers.get_above_threshold_speed(g['orograph_f32'], 0.75)
+    starts = np.stack([g['start_rows'], g['start_cols']], 1)
+    for spl in (0, 64):
+        res = movmodel.simulate_tracks(0., starts, (500, 600), 1, 1., upd, g['potential'],
+                                       seed=int(g['seed']), use_table=True, ring=ring,
+                                       steps_per_launch=spl)
+        lens, ends, hist = _no_traj_result(res)
+        assert np.array_equal(lens, g['lengths'])
+        assert np.array_equal(ends, g['ends'])
+        assert np.array_equal(hist, g['hist'].view(np.uint32))
+
+
+@pytest.mark.parametrize('tag', ['ff_m1', 'ff_d135_m2', 'ff_m1_nu05'])
+def test_ring_table_g7_cases(gpu, golden, tag):
+    """memory 1 cases use the ring table; others must be refused loudly."""
+    from ssrs_amd import movmodel
+    g = golden('g7_tracks.npz')
+    dirn, mem, nu, has_u, has_p = g[tag + '_params']
+    starts = np.stack([g['start_rows'], g['start_cols']], 1)
+    args = (float(dirn), starts, (96, 128), int(mem), float(nu), g['updraft'],
+            g['potential'] if has_p else None)
+    if int(mem) == 1 and float(nu) == 1.0:
+        res = movmodel.simulate_tracks(*args, seed=int(g['seed']), use_table=True, ring=True,
+                                       steps_per_launch=16)
+        assert np.array_equal(res.lengths.cpu().numpy(), g[tag + '_lengths'])
+    else:
+        with pytest.raises(ValueError):
+            movmodel.simulate_tracks(*args, seed=int(g['seed']), use_table=True, ring=True)
+
+
+@pytest.mark.parametrize('case', ['rough', 'nan_zero', 'updraft_only', 'tiny', 'huge'])
+def test_ring_table_vs_c_oracle(gpu, case):
+    """Fresh inputs incl. the rows the fast path must hand to the exact one:
+    NaN (poisoned) and all-zero rows, weights below the f32 range, f32 overflow."""
+    from ssrs_amd import movmodel
+    from oracle import c_oracle
+    rows, cols = 150, 170
+    upd, pot = _random_field_case(rows, cols, 31)
+    if case == 'nan_zero':
+        upd = upd.copy(); pot = pot.copy()
+        upd[20:25, 30:40] = np.nan
+        pot[60:62, 10:160] = np.nan
+        pot[90:110, :] = 3.0                       # zero differences
+    elif case == 'updraft_only':
+        pot = None
+    elif case == 'tiny':
+        pot = (pot.astype(np.float64) * 1e-37).astype(np.float32)    # weights ~1e-40 .. 1e-37
+    elif case == 'huge':
+        upd = upd * 1e30
+        pot = (pot.astype(np.float64) * 1e30).astype(np.float32)     # weights up to ~1e62: f32 inf
+    rng = np.random.default_rng(5)
+    n = 900
+    starts = np.stack([rng.integers(0, rows, n), rng.integers(0, cols, n)], 1)
+    ref = c_oracle.simulate_tracks(20., starts, (rows, cols), 1, 1., upd, pot, seed=11,
+                                   track_id_base=77, want_traj=False)
+    for ring in (False, True):
+        res = movmodel.simulate_tracks(20., starts, (rows, cols), 1, 1., upd, pot, seed=11,
+                                       track_id_base=77, use_table=True, ring=ring,
+                                       steps_per_launch=32)
+        lens, ends, hist = _no_traj_result(res)
+        assert np.array_equal(lens, ref['lengths']), (case, ring)
+        assert np.array_equal(ends, ref['ends']), (case, ring)
+        assert np.array_equal(hist, ref['hist']), (case, ring)
+
+
+def test_ring_table_large_batch_equals_f64_table(gpu):
+    """Binning + per-XCD lists + ring table at a size where all of them are on."""
+    from ssrs_amd import movmodel
+    rows, cols = 600, 900
+    upd, pot = _random_field_case(rows, cols, 3)
+    rng = np.random.default_rng(8)
+    n = 20000
+    starts = np.stack([rng.integers(1, 12, n), rng.integers(0, cols, n)], 1)
+    a = _no_traj_result(movmodel.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=3,
+                                                 use_table=True, ring=False))
+    b = _no_traj_result(movmodel.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=3,
+                                                 use_table=True, ring=True))
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    assert int(b[2].sum()) == int(b[0].sum())
