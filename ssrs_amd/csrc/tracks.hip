@@ -1168,14 +1168,25 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_visits(const uint32_t *__re
     const uint32_t base = brow * cols;
     const uint32_t wcells = static_cast<uint32_t>(wrows) * cols;
     uint32_t stray = 0;
+    // eight loads in flight per thread: the loop is bound by the latency of the visit
+    // buffer (just written by the stepper), not by the LDS atomics
+    constexpr int kU = 8;
 #pragma unroll
     for (int x = 0; x < kXcd; ++x)
-        for (uint32_t j = threadIdx.x; j < nslots[x]; j += kBinThreads) {
-            const uint32_t c = v[x * cap + j];
-            if (c >= ncell) continue;                  // idle slot
-            const uint32_t off = c - base;
-            if (off < wcells) atomicAdd(&bins[off], 1u);
-            else { atomicAdd(&hist[c], 1u); ++stray; }
+        for (uint32_t j = threadIdx.x; j < nslots[x]; j += kBinThreads * kU) {
+            uint32_t c[kU];
+#pragma unroll
+            for (int q = 0; q < kU; ++q) {
+                const uint32_t jj = j + q * kBinThreads;
+                c[q] = jj < nslots[x] ? v[x * cap + jj] : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int q = 0; q < kU; ++q) {
+                if (c[q] >= ncell) continue;           // idle slot
+                const uint32_t off = c[q] - base;
+                if (off < wcells) atomicAdd(&bins[off], 1u);
+                else { atomicAdd(&hist[c[q]], 1u); ++stray; }
+            }
         }
     // stray count -> host: when the batch no longer moves as a front (tracks
     // trapped or scattered) the host switches back to in-stepper atomics
@@ -1183,9 +1194,16 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_visits(const uint32_t *__re
     for (int off = 32; off > 0; off >>= 1) stray += __shfl_down(stray, off);
     if ((threadIdx.x & 63) == 0 && stray) atomicAdd(&ctl->strays, static_cast<unsigned long long>(stray));
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k < wcells && base + k < ncell; k += kBinThreads) {
-        const uint32_t n = bins[k];
-        if (n) atomicAdd(&hist[base + k], n);
+    for (uint32_t k = threadIdx.x; k < wcells; k += kBinThreads * 4) {
+        uint32_t n[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t kk = k + q * kBinThreads;
+            n[q] = (kk < wcells && base + kk < ncell) ? bins[kk] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (n[q]) atomicAdd(&hist[base + k + q * kBinThreads], n[q]);
     }
 }
 
