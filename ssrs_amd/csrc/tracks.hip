@@ -355,6 +355,26 @@ __device__ __forceinline__ int choose_three_ring(float fa, float fb, float fc, d
     return near ? -1 : sel;
 }
 
+// First tier of the ring decision, entirely in f32 (the f64 / conversion
+// instructions were the larger part of a step's VALU time): uf = u truncated to its
+// top 24 bits.  Error budget relative to the true total A: table values 2^-24 each,
+// two f32 additions 2^-24 each, u truncation and product rounding 2^-24 each, the
+// subtractions 2^-24: |(C_j - u A) - (c_j - uf acc)| <= 2^-21 A.  Band 2^-19 acc; a
+// candidate boundary inside the band (probability ~8e-6 per step) goes to
+// choose_three_ring (f64 sums, full u, band 2^-21), which may go to the exact sequence.
+__device__ __forceinline__ int choose_three_ring_f32(float fa, float fb, float fc, float uf)
+{
+    const float cb = fa + fb;
+    const float acc = cb + fc;
+    const float ut = uf * acc;
+    const float band = acc * 0x1p-19f;
+    const float da = fa - ut, db = cb - ut;
+    const int sel = da > 0.f ? 0 : (db > 0.f ? 1 : 2);
+    const float closest = fminf(fabsf(da), fabsf(db));
+    const bool near = !(acc > 0x1p-90f) || !(closest > band);
+    return near ? -1 : sel;
+}
+
 // Raw 3x3 move weights of movmodel.py:292-306 at an interior cell.
 template <bool HAS_POT>
 __device__ __forceinline__ void window_weights(const double *__restrict__ updraft,
@@ -978,10 +998,10 @@ __global__ __launch_bounds__(kBlock) void k_step_lean(const StepArgs a)
         } else {
             w0 = pend_a; w1 = pend_b;
         }
-        const double u = words_to_uniform(w0, w1);
         // ---- decision among the three admissible cells
         int nrow, ncol;
         if (RING) {
+            const float uf = static_cast<float>(w0 >> 8) * 0x1p-24f;     // top 24 bits of u, exact
             const uint32_t ord = static_cast<uint32_t>(kRingOrder >> (6 * (rc & 7u))) & 63u;
             // (x0, x1, x2) -> ascending k.  Only four orders occur (static_asserts below);
             // written as two-way selects on the bit patterns so that they stay v_cndmask
@@ -991,10 +1011,19 @@ __global__ __launch_bounds__(kBlock) void k_step_lean(const StepArgs a)
             const uint32_t ba = (rot || rev) ? b2 : (swp ? b1 : b0);
             const uint32_t bb = (rot || swp) ? b0 : b1;
             const uint32_t bc = rev ? b0 : (rot ? b1 : b2);
-            const int sel = choose_three_ring(__uint_as_float(ba), __uint_as_float(bb), __uint_as_float(bc), u);
+            int sel = choose_three_ring_f32(__uint_as_float(ba), __uint_as_float(bb), __uint_as_float(bc), uf);
+            bool slow = st && (sel < 0 || rc == 8u);
+            double u = 0.0;
+            if (__builtin_expect(__any(slow), 0)) {
+                // second tier: f64 sums and the full 53-bit u (band 2^-21)
+                u = words_to_uniform(w0, w1);
+                if (slow) {
+                    sel = choose_three_ring(__uint_as_float(ba), __uint_as_float(bb), __uint_as_float(bc), u);
+                    slow = sel < 0 || rc == 8u;
+                }
+            }
             // ring position of the chosen cell: rc - 1 + (which x it was)
             uint32_t nc = (rc + 7u + ((ord >> (2 * (sel < 0 ? 0 : sel))) & 3u)) & 7u;
-            const bool slow = st && (sel < 0 || rc == 8u);
             if (__builtin_expect(__any(slow), 0)) {
                 if (slow) {
                     // first step of a track (8 admissible cells), near-ties, poisoned rows:
@@ -1014,6 +1043,7 @@ __global__ __launch_bounds__(kBlock) void k_step_lean(const StepArgs a)
             ncol = ec + static_cast<int>((kRingDc >> (2 * nc)) & 3u) - 1;
             rc = st ? nc : rc;
         } else {
+            const double u = words_to_uniform(w0, w1);
             const uint32_t last = dirs & 0xFu;
             const int sel = choose_three_fast(ta, tb, tc, u);
             const uint32_t slot = (cand >> (3 * (sel < 0 ? 0 : sel))) & 7u;
