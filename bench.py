@@ -236,6 +236,8 @@ def main():
     # checksum of checksums: every trajectory point was counted exactly once
     assert int(hist.sum().item()) == total_steps_all // K + n_total, 'histogram checksum failed'
     kernel_s = acc['step_kernel_ms'] / 1e3
+    # bytes the chosen data path really requests per step (read + 4 B visit / histogram update)
+    moved_bytes = 76 if args.direct else (92 if args.exact_only else (28 if args.f64_table else 16))
     achieved = acc['steps'] * STEP_BYTES / kernel_s / 1e9 if kernel_s > 0 else 0.0
     raster_s = acc['raster_ms'] / 1e3 / K
     out = {
@@ -274,7 +276,8 @@ def main():
             'stepper_wall': acc['step_wall_ms'] / K,
         },
         'roofline': {
-            'kernel': 'k_step_tracks (K2 stepper, rank 0)',
+            'kernel': ('k_step_tracks' if (args.direct or args.f64_table or args.exact_only)
+                       else 'k_step_lean<ring>') + ' (K2 stepper, rank 0)',
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBPS,
             'traffic': None,
@@ -282,6 +285,13 @@ def main():
             'launches': acc['launches'] // K,
             'avg_launch_ms': acc['step_kernel_ms'] / max(acc['launches'], 1),
             'avg_bytes_per_launch': acc['steps'] * STEP_BYTES / max(acc['launches'], 1),
+            # the 76 B/step of SURVEY 8(d) is the gather volume of the reference's formulation
+            # (18 window reads + 1 point); the shipped path precomputes the windows into a table
+            # and moves MOVED_BYTES per step, so a model fraction near or above 1 does NOT mean
+            # HBM is saturated: the kernel is bound by the dependent chain of a step
+            'moved_bytes_per_step': moved_bytes,
+            'moved_gbps': acc['steps'] * moved_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0,
+            'moved_frac': (acc['steps'] * moved_bytes / kernel_s / 1e9 / HBM_PEAK_GBPS) if kernel_s > 0 else 0.0,
         },
     }
     pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')

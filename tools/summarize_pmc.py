@@ -43,7 +43,7 @@ def main(fetch_dir, write_dir, out_json, title):
         corr = (2 * f_kb + w_kb) * 1024
         rec[name] = {'launches': fe[name][1], 'fetch_kb': f_kb, 'write_kb': w_kb, 'corrected_bytes': corr}
         print(f'| `{name}` | {fe[name][1]} | {f_kb:.0f} | {w_kb:.0f} | {corr / 1e6:.1f} MB |')
-    step = next((v for k, v in rec.items() if 'k_step_tracks' in k), None)
+    step = next((v for k, v in rec.items() if 'k_step_' in k), None)   # k_step_lean / k_step_tracks
     out = {'k_step_tracks_bytes_per_launch': step['corrected_bytes'] if step else None,
            'source': f'{title}: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, gfx950 half-count '
                      'correction on FETCH_SIZE, separate --pmc passes',
