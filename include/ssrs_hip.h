@@ -253,9 +253,14 @@ typedef struct SsrsSolveStats {
 } SsrsSolveStats;
 
 #define SSRS_SOLVE_NO_AMG 1  /* plain BiCGStab (A/B switch; stalls on real rasters) */
-#define SSRS_SOLVE_K_CYCLE 2 /* K-cycle on the first three coarse levels instead of
-                               the V-cycle (experimental: costs 5x per iteration and
-                               has not reduced the iteration count so far) */
+#define SSRS_SOLVE_K_CYCLE 2 /* K-cycle (two flexible-CG steps per coarse solve) on the
+                               first coarse levels instead of the V-cycle; depth in flag
+                               bits 12-15 (0 = 3 levels) */
+#define SSRS_SOLVE_ONE_SIDED 4 /* aggregation strength relative to the row maximum only
+                                 (A/B switch: the previous criterion; pairs dead with live
+                                 cells and needs 2-3x the iterations) */
+/* flags bits 4-6: extra pairs of Jacobi sweeps; bits 8-11: strict matching rounds of
+ * the one-sided criterion (0 = 4) */
 
 size_t ssrs_potential_workspace_bytes(int rows, int cols);
 

@@ -12,7 +12,8 @@ struct AmgLevel {
     int *rowptr = nullptr, *col = nullptr;
     double *val = nullptr, *dinv = nullptr;
     int *agg = nullptr;        // fine node -> coarse node (-1: isolated row), NULL on the last level
-    int *members = nullptr;    // coarse node -> up to 3 fine nodes
+    int *memptr = nullptr;     // coarse node I -> its fine nodes memidx[memptr[I] .. memptr[I+1])
+    int *memidx = nullptr;
     double *x = nullptr, *xt = nullptr, *b = nullptr, *r = nullptr;
     // K-cycle scratch (levels 1 .. kdepth)
     double *kb = nullptr, *c1 = nullptr, *v1 = nullptr, *v2 = nullptr;
@@ -25,6 +26,7 @@ struct AmgHierarchy {
     size_t workspace_used = 0;
     void *graph_exec = nullptr;    // hipGraphExec_t of one captured cycle (NULL: direct launches)
     bool graph_tried = false;
+    bool symmetric = true;         // symmetric strength of connection (amg.hip: strong_link)
     int strong_rounds = 4;         // matching rounds restricted to strong couplings (of 8)
     int kdepth = 0;                // coarse levels 1..kdepth use the K-cycle (0 = V-cycle)
     int sweeps = 1;                // pairs of Jacobi sweeps before and after the coarse correction

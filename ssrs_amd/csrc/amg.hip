@@ -15,10 +15,13 @@
 //             weights (the reference's east-edge quirk lives only in the outer
 //             Krylov operator, potential.hip)
 //   coarsen   pairwise aggregation: every unmatched node proposes to its
-//             strongest unmatched neighbour (>= 0.25 of the row maximum, ties
-//             broken by a symmetric hash), mutual proposals pair up, 8 rounds;
-//             leftover nodes may join an adjacent pair (the pair keeps the
-//             highest-priority applicant: atomicMax, order independent)
+//             strongest unmatched neighbour that is SYMMETRICALLY strong
+//             (a_ij^2 >= (0.25/8)^2 a_ii a_jj: never across the live/dead phases;
+//             ties broken by a symmetric hash), mutual proposals pair up, 8
+//             rounds; leftover nodes join the aggregate of their best matched
+//             neighbour, any number per aggregate (each node decides alone:
+//             order independent); once strict matching stalls, any positive
+//             coupling may pair
 //   Galerkin  P^T A P by radix-sorting (I,J) keys + reduce-by-key (hipCUB)
 //   cycle     V(2,2), damped Jacobi (omega 0.7), dense inverse on the coarsest
 //             level (<= 1024 nodes, Gauss-Jordan on the device)
@@ -161,12 +164,30 @@ __device__ __forceinline__ unsigned long long edge_priority(double w, uint32_t i
     return (b & ~0xFFFFFull) | (edge_hash(i, j) & 0xFFFFFu);
 }
 
+// Strength of connection.  The rasters are two-phase media: "live" cells with
+// conductances ~1 and "dead" cells (zero usable updraft) with 1e-8, both phases
+// percolating.  A dead cell sees its link to a live neighbour as strong as any of
+// its links (all 1e-8), so a criterion relative to the ROW maximum alone lets dead
+// and live nodes pair up once the live node has run out of live partners; such
+// mixed aggregates cost 2-3x the V-cycle iterations and break the K-cycle
+// (tools/amg_experiment6.py: 497 vs 162 V-cycles, K-cycle 500+ vs 30).  The
+// symmetric criterion a_ij^2 >= (theta/8)^2 a_ii a_jj never pairs across the phases.
+//   mode 0: symmetric;  1: relative to the row maximum (previous behaviour);
+//   2: any positive coupling (after symmetric coarsening has stalled)
+__device__ __forceinline__ bool strong_link(double w, double wmax, double di_inv, double dj_inv, int mode)
+{
+    if (mode == 0) return w * w * di_inv * dj_inv >= (kTheta / 8.0) * (kTheta / 8.0);
+    if (mode == 1) return w >= kTheta * wmax;
+    return true;
+}
+
 // every unmatched node proposes to its best unmatched strong neighbour
 __global__ __launch_bounds__(kBlock) void k_propose(const int *__restrict__ rowptr,
                                                    const int *__restrict__ col,
                                                    const double *__restrict__ val, int n,
                                                    const int *__restrict__ match,
-                                                   int *__restrict__ prop, double theta)
+                                                   int *__restrict__ prop,
+                                                   const double *__restrict__ dinv, int mode)
 {
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         int best = -1;
@@ -178,7 +199,7 @@ __global__ __launch_bounds__(kBlock) void k_propose(const int *__restrict__ rowp
             for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) {
                 const int j = col[p];
                 const double w = -val[p];
-                if (j == i || !(w > 0.0) || w < theta * wmax || match[j] >= 0) continue;
+                if (j == i || !(w > 0.0) || match[j] >= 0 || !strong_link(w, wmax, dinv[i], dinv[j], mode)) continue;
                 const unsigned long long pr = edge_priority(w, i, j);
                 if (pr > bp) { bp = pr; best = j; }
             }
@@ -196,79 +217,55 @@ __global__ __launch_bounds__(kBlock) void k_accept(int n, const int *__restrict_
     }
 }
 
-// leftover nodes apply to the pair of their strongest matched neighbour; the
-// pair's leader keeps the best applicant (order-independent atomicMax)
-__global__ __launch_bounds__(kBlock) void k_apply_join(const int *__restrict__ rowptr,
-                                                      const int *__restrict__ col,
-                                                      const double *__restrict__ val, int n,
-                                                      const int *__restrict__ match,
-                                                      unsigned long long *__restrict__ third)
+// Leftover nodes join the aggregate of their best MATCHED neighbour, any number per
+// aggregate: a pocket of dead cells that has collapsed to one node hangs on nodes of
+// the live cluster by couplings that are weak seen from the live side, so it never
+// finds a mutual partner; with a bounded number of joins per pair such leaves pile up
+// around hubs and coarsening stalls (1000 x 1200 raster: stuck at 9936 nodes).
+// Symmetric-strong neighbours win over merely row-strong ones.  Each node decides for
+// itself, so the result does not depend on execution order.
+__global__ __launch_bounds__(kBlock) void k_join(const int *__restrict__ rowptr,
+                                                const int *__restrict__ col,
+                                                const double *__restrict__ val, int n,
+                                                const int *__restrict__ match,
+                                                const double *__restrict__ dinv,
+                                                int *__restrict__ joined_to, int *__restrict__ flag)
 {
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        if (match[i] >= 0 || rowptr[i + 1] - rowptr[i] <= 1) continue;
-        double wmax = 0.0;
-        for (int p = rowptr[i]; p < rowptr[i + 1]; ++p)
-            if (col[p] != i && -val[p] > wmax) wmax = -val[p];
-        unsigned long long bp = 0;
-        int best = -1;
-        for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) {
-            const int j = col[p];
-            const double w = -val[p];
-            if (j == i || !(w > 0.0) || w < kTheta * wmax || match[j] < 0) continue;
-            const unsigned long long pr = edge_priority(w, i, j);
-            if (pr > bp) { bp = pr; best = j; }
-        }
-        if (best >= 0) {
-            const int leader = best < match[best] ? best : match[best];
-            // priority in the high bits, applicant id in the low 32
-            const unsigned long long key = (bp & 0xFFFFFFFF00000000ull) | static_cast<uint32_t>(i);
-            atomicMax(&third[leader], key);
-        }
-    }
-}
-
-// flag = 1 for aggregate leaders (pair leader = smaller index; singles that did
-// not join anyone; isolated rows get no aggregate at all)
-__global__ __launch_bounds__(kBlock) void k_leader_flags(const int *__restrict__ rowptr, int n,
-                                                        const int *__restrict__ match,
-                                                        const unsigned long long *__restrict__ third,
-                                                        int *__restrict__ joined_to,
-                                                        int *__restrict__ flag)
-{
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        joined_to[i] = -1;
         const bool isolated = rowptr[i + 1] - rowptr[i] <= 1;
-        int f = 0;
+        int join = -1, f = 0;
         if (!isolated) {
-            if (match[i] >= 0) f = i < match[i] ? 1 : 0;
-            else f = 1;                      // provisional: cleared below if it joined a pair
-        }
-        flag[i] = f;
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void k_resolve_join(int n, const int *__restrict__ match,
-                                                        const unsigned long long *__restrict__ third,
-                                                        int *__restrict__ joined_to,
-                                                        int *__restrict__ flag)
-{
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        if (match[i] >= 0 && i < match[i] && third[i] != 0ull) {
-            const int applicant = static_cast<int>(third[i] & 0xFFFFFFFFull);
-            if (applicant >= 0 && applicant < n) {     // always true; guards the index
-                joined_to[applicant] = i;
-                flag[applicant] = 0;
+            if (match[i] >= 0) {
+                f = i < match[i] ? 1 : 0;                 // pair leader = smaller index
+            } else {
+                double wmax = 0.0;
+                for (int p = rowptr[i]; p < rowptr[i + 1]; ++p)
+                    if (col[p] != i && -val[p] > wmax) wmax = -val[p];
+                unsigned long long bp = 0;
+                int best = -1;
+                for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) {
+                    const int j = col[p];
+                    const double w = -val[p];
+                    if (j == i || !(w > 0.0) || match[j] < 0 || w < kTheta * wmax) continue;
+                    unsigned long long pr = edge_priority(w, i, j) >> 1;
+                    if (strong_link(w, wmax, dinv[i], dinv[j], 0)) pr |= 1ull << 63;
+                    if (pr > bp) { bp = pr; best = j; }
+                }
+                if (best >= 0) join = best < match[best] ? best : match[best];
+                else f = 1;                               // stays a singleton aggregate
             }
         }
+        joined_to[i] = join;
+        flag[i] = f;
     }
 }
 
 __global__ __launch_bounds__(kBlock) void k_assign_agg(const int *__restrict__ rowptr, int n,
                                                       const int *__restrict__ match,
                                                       const int *__restrict__ joined_to,
-                                                      const int *__restrict__ flag,
                                                       const int *__restrict__ cid,   // exclusive scan of flag
-                                                      int *__restrict__ agg, int *__restrict__ members)
+                                                      int *__restrict__ agg,
+                                                      unsigned long long *__restrict__ keys)
 {
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const bool isolated = rowptr[i + 1] - rowptr[i] <= 1;
@@ -278,22 +275,27 @@ __global__ __launch_bounds__(kBlock) void k_assign_agg(const int *__restrict__ r
             if (match[i] >= 0) leader = i < match[i] ? i : match[i];
             else if (joined_to[i] >= 0) leader = joined_to[i];
             a = cid[leader];
-            if (flag[i]) {                                   // leader writes the member list
-                members[3 * a + 0] = i;
-                members[3 * a + 1] = match[i] >= 0 ? match[i] : -1;
-                members[3 * a + 2] = -1;
-            }
         }
         agg[i] = a;
+        // (aggregate, member) keys; sorted, they are the member lists of the restriction
+        keys[i] = a >= 0 ? (static_cast<unsigned long long>(a) << 32) | static_cast<uint32_t>(i) : ~0ull;
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_third_member(int n, const int *__restrict__ joined_to,
-                                                        const int *__restrict__ agg,
-                                                        int *__restrict__ members)
+// member lists from the sorted keys: memidx[p] = fine node, memptr[a] = first p of aggregate a
+__global__ __launch_bounds__(kBlock) void k_member_lists(const unsigned long long *__restrict__ keys, int n,
+                                                        int nc, int *__restrict__ memptr,
+                                                        int *__restrict__ memidx)
 {
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
-        if (joined_to[i] >= 0) members[3 * agg[i] + 2] = i;
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < n; p += gridDim.x * kBlock) {
+        const unsigned long long k = keys[p];
+        memidx[p] = static_cast<int>(k & 0xFFFFFFFFull);
+        const bool parked = k == ~0ull;
+        const int a = parked ? nc : static_cast<int>(k >> 32);
+        const bool first = p == 0 || (keys[p - 1] >> 32) != (k >> 32);
+        if (first) memptr[a] = p;                         // the parked bucket marks the end
+        if (p == n - 1 && !parked) memptr[nc] = n;
+    }
 }
 
 // Galerkin keys: one (I, J) key per fine entry whose ends both have aggregates
@@ -367,15 +369,14 @@ __global__ __launch_bounds__(kBlock) void k_residual(const int *__restrict__ row
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_restrict(const int *__restrict__ members,
+__global__ __launch_bounds__(kBlock) void k_restrict(const int *__restrict__ memptr,
+                                                    const int *__restrict__ memidx,
                                                     const double *__restrict__ r, int nc,
                                                     double *__restrict__ bc)
 {
     for (int I = blockIdx.x * kBlock + threadIdx.x; I < nc; I += gridDim.x * kBlock) {
-        double s = r[members[3 * I]];
-        const int m1 = members[3 * I + 1], m2 = members[3 * I + 2];
-        if (m1 >= 0) s += r[m1];
-        if (m2 >= 0) s += r[m2];
+        double s = 0.0;                                   // members in index order: reproducible
+        for (int p = memptr[I]; p < memptr[I + 1]; ++p) s += r[memidx[p]];
         bc[I] = s;
     }
 }
@@ -642,6 +643,7 @@ int amg_setup(AmgHierarchy &h, const double *cond, const uint8_t *fixed, int row
     void *cub_tmp = bump.take(cub_tb);
     if (!cub_tmp) return set_error(SSRS_ERR_INVALID, "amg: workspace exhausted (cub)");
 
+    bool permissive = false;
     for (int lev = 0;; ++lev) {
         const int n = L.n;
         AMG_TAKE(L.dinv, double, n);
@@ -660,47 +662,56 @@ int amg_setup(AmgHierarchy &h, const double *cond, const uint8_t *fixed, int row
         }
         hipLaunchKernelGGL(k_dinv, dim3(grid_for(n)), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, n, L.dinv);
         L.agg = nullptr;
-        L.members = nullptr;
+        L.memptr = nullptr;
+        L.memidx = nullptr;
         L.nc = 0;
         if ((n <= kMaxDense && lev > 0) || lev >= 48) { h.levels.push_back(L); break; }
 
         // ---- pairwise aggregation
         int *match, *prop, *joined, *flag, *cid;
-        unsigned long long *third;
         AMG_TAKE(L.agg, int, n);
         AMG_TAKE(match, int, n);
         AMG_TAKE(prop, int, n);
         AMG_TAKE(joined, int, n);
         AMG_TAKE(flag, int, n + 1);
         AMG_TAKE(cid, int, n + 1);
-        AMG_TAKE(third, unsigned long long, n);
-        SSRS_HIP_CHECK(hipMemsetAsync(match, 0xFF, sizeof(int) * n, st));
-        SSRS_HIP_CHECK(hipMemsetAsync(third, 0, sizeof(unsigned long long) * n, st));
-        for (int round = 0; round < kMatchRounds; ++round) {
-            hipLaunchKernelGGL(k_propose, dim3(grid_for(n)), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, n,
-                               match, prop, round < h.strong_rounds ? kTheta : 0.0);
-            hipLaunchKernelGGL(k_accept, dim3(grid_for(n)), dim3(kBlock), 0, st, n, prop, match);
-        }
-        hipLaunchKernelGGL(k_apply_join, dim3(grid_for(n)), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, n, match, third);
-        hipLaunchKernelGGL(k_leader_flags, dim3(grid_for(n)), dim3(kBlock), 0, st, L.rowptr, n, match, third, joined, flag);
-        hipLaunchKernelGGL(k_resolve_join, dim3(grid_for(n)), dim3(kBlock), 0, st, n, match, third, joined, flag);
-        SSRS_HIP_CHECK(hipMemsetAsync(flag + n, 0, sizeof(int), st));
-        {
-            size_t tb = cub_tb;
-            SSRS_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, tb, flag, cid, n + 1, st));
-        }
         int nc = 0;
-        SSRS_HIP_CHECK(hipMemcpyAsync(&nc, cid + n, sizeof(int), hipMemcpyDeviceToHost, st));
-        SSRS_HIP_CHECK(hipStreamSynchronize(st));
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            SSRS_HIP_CHECK(hipMemsetAsync(match, 0xFF, sizeof(int) * n, st));
+            for (int round = 0; round < kMatchRounds; ++round) {
+                // symmetric (default): every round strict, any positive coupling once the
+                // strict coarsening has stalled; one-sided: strong_rounds strict, then any
+                const int mode = h.symmetric ? (permissive ? 2 : 0) : (round < h.strong_rounds ? 1 : 2);
+                hipLaunchKernelGGL(k_propose, dim3(grid_for(n)), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, n,
+                                   match, prop, L.dinv, mode);
+                hipLaunchKernelGGL(k_accept, dim3(grid_for(n)), dim3(kBlock), 0, st, n, prop, match);
+            }
+            hipLaunchKernelGGL(k_join, dim3(grid_for(n)), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, n, match,
+                               L.dinv, joined, flag);
+            SSRS_HIP_CHECK(hipMemsetAsync(flag + n, 0, sizeof(int), st));
+            {
+                size_t tb = cub_tb;
+                SSRS_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, tb, flag, cid, n + 1, st));
+            }
+            SSRS_HIP_CHECK(hipMemcpyAsync(&nc, cid + n, sizeof(int), hipMemcpyDeviceToHost, st));
+            SSRS_HIP_CHECK(hipStreamSynchronize(st));
+            if (!(h.symmetric && !permissive && (nc == 0 || nc > 0.85 * n))) break;
+            permissive = true;                     // strict coarsening stalled: redo this level
+        }
         if (nc == 0 || nc > 0.93 * n) {           // nothing (left) to coarsen
             L.agg = nullptr;
             h.levels.push_back(L);
             break;
         }
-        AMG_TAKE(L.members, int, 3 * static_cast<size_t>(nc));
-        hipLaunchKernelGGL(k_assign_agg, dim3(grid_for(n)), dim3(kBlock), 0, st, L.rowptr, n, match, joined, flag,
-                           cid, L.agg, L.members);
-        hipLaunchKernelGGL(k_third_member, dim3(grid_for(n)), dim3(kBlock), 0, st, n, joined, L.agg, L.members);
+        AMG_TAKE(L.memptr, int, static_cast<size_t>(nc) + 1);
+        AMG_TAKE(L.memidx, int, n);
+        hipLaunchKernelGGL(k_assign_agg, dim3(grid_for(n)), dim3(kBlock), 0, st, L.rowptr, n, match, joined, cid,
+                           L.agg, keys_a);
+        {
+            size_t tb = cub_tb;
+            SSRS_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(cub_tmp, tb, keys_a, keys_b, n, 0, 64, st));
+        }
+        hipLaunchKernelGGL(k_member_lists, dim3(grid_for(n)), dim3(kBlock), 0, st, keys_b, n, nc, L.memptr, L.memidx);
         L.nc = nc;
 
         // ---- Galerkin coarse matrix: sort (I,J) keys, sum duplicates
@@ -792,7 +803,7 @@ static void cycle(AmgHierarchy &h, size_t lev, hipStream_t st)
     }
     hipLaunchKernelGGL(k_residual, dim3(g), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.b, L.x, n, L.r);
     AmgLevel &C = h.levels[lev + 1];
-    hipLaunchKernelGGL(k_restrict, dim3(grid_for(C.n)), dim3(kBlock), 0, st, L.members, L.r, C.n, C.b);
+    hipLaunchKernelGGL(k_restrict, dim3(grid_for(C.n)), dim3(kBlock), 0, st, L.memptr, L.memidx, L.r, C.n, C.b);
     solve_level(h, lev + 1, st);
     hipLaunchKernelGGL(k_prolong_add, dim3(g), dim3(kBlock), 0, st, L.agg, C.x, n, L.x);
     // post-smoothing

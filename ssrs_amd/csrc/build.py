@@ -30,7 +30,7 @@ def build(force=False, verbose=False):
         o = os.path.splitext(s)[0] + '.o'
         objs.append(o)
         if not force and os.path.exists(o) and os.path.getmtime(o) >= _newest(
-                [s, deps[-1], deps[-2]]):
+                [s, deps[-1], deps[-2], deps[-3]]):     # every header: amg.h, common.h, ssrs_hip.h
             continue
         cmd = [hipcc] + FLAGS + ['-c', s, '-o', o]
         if verbose:

@@ -393,7 +393,8 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
         ~AmgGuard() { amg_release(h); }
     } amg_guard{amg};
     amg.sweeps = 1 + ((flags >> 4) & 7);
-    amg.kdepth = (flags & SSRS_SOLVE_K_CYCLE) ? 3 : 0;
+    amg.kdepth = (flags & SSRS_SOLVE_K_CYCLE) ? (((flags >> 12) & 15) ? ((flags >> 12) & 15) : 3) : 0;
+    amg.symmetric = (flags & SSRS_SOLVE_ONE_SIDED) == 0;
     amg.strong_rounds = ((flags >> 8) & 15) ? ((flags >> 8) & 15) : 4;
     if (use_amg) {
         char *amg_base = base + 10 * vec_bytes(n);

@@ -61,7 +61,8 @@ def dirichlet_rasters(move_dirn, grid_shape):
 
 
 def solve_potential(updraft, move_dirn, rel_tol=1e-12, max_iterations=2000,
-                    initial_guess=None, return_stats=False, use_amg=True, extra_sweeps=0, cycle='V', strong_rounds=0):
+                    initial_guess=None, return_stats=False, use_amg=True, extra_sweeps=0, cycle='V',
+                    strong_rounds=0, kdepth=0, one_sided=False):
     """MovModel(...).solve_sparse_linear_system equivalent -> f32 (rows, cols).
 
     `updraft` is the conductivity raster (usable updraft, f64); numpy in ->
@@ -81,7 +82,8 @@ def solve_potential(updraft, move_dirn, rel_tol=1e-12, max_iterations=2000,
         nat.ptr(cond), nat.ptr(mask), nat.ptr(vals), nat.ptr(guess), nat.ptr(out),
         rows, cols, C.c_double(rel_tol), int(max_iterations),
         (0 if use_amg else nat.SSRS_SOLVE_NO_AMG) | (int(extra_sweeps) << 4) |
-        (2 if cycle == 'K' else 0) | (int(strong_rounds) << 8), nat.ptr(ws),
+        (2 if cycle == 'K' else 0) | (int(strong_rounds) << 8) | (int(kdepth) << 12) |
+        (4 if one_sided else 0), nat.ptr(ws),
         C.c_size_t(nbytes), C.byref(stats), stream_ptr()))
     if not stats.converged:
         import warnings
