@@ -111,3 +111,29 @@ def test_plain_bicgstab_switch_still_works_on_benign_problem(gpu):
                                   return_stats=True, use_amg=amg)
         assert st['converged'], st
         np.testing.assert_allclose(pot, ramp, rtol=0, atol=2e-3 if not amg else 2e-4)
+
+
+def test_potential_two_phase_raster_iteration_budget(gpu):
+    """Regression guard for the aggregation criterion (amg.hip: strong_link): a 10-m
+    synthetic raster is a two-phase medium (about half the cells have zero usable
+    updraft).  With the symmetric strength of connection and unbounded joins the
+    V-cycle needs ~100 iterations; the one-sided criterion does not converge in 850.
+    Also: the answer is a discrete harmonic function, so it obeys the maximum
+    principle, and K-cycle / V-cycle agree."""
+    import torch
+    from ssrs_amd import layers
+    from ssrs_amd.potential import solve_potential
+    from ssrs_amd.synthetic import synthetic_dem
+    dem = torch.from_numpy(synthetic_dem((700, 900), 10.)).cuda()
+    _, upd = layers.updraft_from_dem(dem, 10., 10., 270., threshold=0.75)
+    dead = float((upd <= 0).double().mean().item())
+    assert 0.3 < dead < 0.85, dead
+    pot, st = solve_potential(upd, 0., rel_tol=1e-9, max_iterations=400, return_stats=True)
+    assert st['converged'] and st['iterations'] <= 250, st
+    p = pot.cpu().numpy()
+    assert p.min() >= -1e-3 and p.max() <= 1000.001
+    assert abs(p[0].mean() - 1000.) < 1e-3 and abs(p[-1].mean()) < 1e-3      # Dirichlet rows
+    pot_k, st_k = solve_potential(upd, 0., rel_tol=1e-9, max_iterations=400, return_stats=True,
+                                  cycle='K', kdepth=3)
+    assert st_k['converged'], st_k
+    np.testing.assert_allclose(pot_k.cpu().numpy(), p, rtol=0, atol=2e-3)
