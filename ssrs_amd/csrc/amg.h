@@ -30,6 +30,10 @@ struct AmgHierarchy {
     int strong_rounds = 4;         // matching rounds restricted to strong couplings (of 8)
     int kdepth = 0;                // coarse levels 1..kdepth use the K-cycle (0 = V-cycle)
     int sweeps = 1;                // pairs of Jacobi sweeps before and after the coarse correction
+    // level 0 applied matrix-free (amg.hip: L0Stencil)
+    const double *l0_rinv = nullptr;
+    const uint8_t *l0_fixed = nullptr;
+    int l0_rows = 0, l0_cols = 0;
 };
 
 size_t amg_workspace_bytes(int rows, int cols);

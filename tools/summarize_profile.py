@@ -13,7 +13,7 @@ def main(src, title):
     print('| kernel | calls | total ms | avg us | min us | max us | % |')
     print('|---|---:|---:|---:|---:|---:|---:|')
     for r in rows[:12]:
-        name = r['Name'].split('(')[0].replace('void ', '')
+        name = r['Name'].replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '')
         print(f"| `{name}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.3f} | "
               f"{float(r['AverageNs']) / 1e3:.1f} | {float(r['MinNs']) / 1e3:.1f} | "
               f"{float(r['MaxNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |")
