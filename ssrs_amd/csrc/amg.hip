@@ -5,8 +5,8 @@
 // for zero-updraft cells, 2e-10 .. 5 elsewhere).  Conductive clusters that float
 // in dead terrain give eigenvalues ~1e-8; Krylov methods without a coarse space
 // stall (DESIGN.md "K5").  Geometric coarsening fails for the same reason
-// (tools/amg_experiment2.py); aggregation along the STRONG couplings works
-// (tools/amg_experiment4.py) because a floating cluster collapses into few
+// (tests/dev/amg_experiment2.py); aggregation along the STRONG couplings works
+// (tests/dev/amg_experiment4.py) because a floating cluster collapses into few
 // coarse nodes whose level the coarse problem determines directly.
 //
 // Method (all on the device, deterministic -- no float atomics):
@@ -170,7 +170,7 @@ __device__ __forceinline__ unsigned long long edge_priority(double w, uint32_t i
 // its links (all 1e-8), so a criterion relative to the ROW maximum alone lets dead
 // and live nodes pair up once the live node has run out of live partners; such
 // mixed aggregates cost 2-3x the V-cycle iterations and break the K-cycle
-// (tools/amg_experiment6.py: 497 vs 162 V-cycles, K-cycle 500+ vs 30).  The
+// (tests/dev/amg_experiment6.py: 497 vs 162 V-cycles, K-cycle 500+ vs 30).  The
 // symmetric criterion a_ij^2 >= (theta/8)^2 a_ii a_jj never pairs across the phases.
 //   mode 0: symmetric;  1: relative to the row maximum (previous behaviour);
 //   2: any positive coupling (after symmetric coarsening has stalled)
