@@ -132,7 +132,7 @@ typedef struct SsrsTrackParams {
     double scaling_parameter; /* nu; exact parity is claimed for nu == 1 */
     double prior[9];          /* get_directional_probs(move_dirn * pi / 180),
                                  movmodel.py:247-257, computed by the host */
-    int32_t steps_per_launch; /* 0 = default (256) */
+    int32_t steps_per_launch; /* 0 = default (512) */
     int32_t flags;            /* SSRS_TRACKS_* */
 } SsrsTrackParams;
 

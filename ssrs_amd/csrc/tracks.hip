@@ -1251,7 +1251,7 @@ struct Workspace {
     uint32_t cap;                // slots per XCD list
 };
 
-constexpr int kVisitSteps = 256;   // binning mode covers launches of up to this many steps
+constexpr int kVisitSteps = 512;   // binning mode covers launches of up to this many steps
 
 static size_t sort_temp_size(int64_t n)
 {
@@ -1422,7 +1422,7 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
     uint32_t *host_counts = pinned_counts();
     SSRS_REQUIRE(host_counts != nullptr, "ssrs_tracks_simulate: hipHostMalloc failed");
 
-    const int S = p->steps_per_launch > 0 ? p->steps_per_launch : 256;
+    const int S = p->steps_per_launch > 0 ? p->steps_per_launch : 512;
     const bool profile = (p->flags & SSRS_TRACKS_PROFILE) != 0;
     const int mode = table ? MODE_TABLE : (updraft ? (potential ? MODE_FLUIDFLOW : MODE_UPDRAFT)
                                                    : MODE_PRIOR);
@@ -1505,7 +1505,7 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
     // Launch loop.  Launches are queued kBatch deep; the live count of a batch
     // is copied back asynchronously and examined while the next batch runs, so
     // the GPU never waits on the host.  Launches past the end see count 0.
-    constexpr int kBatch = 4, kRing = 8;
+    constexpr int kBatch = 2, kRing = 8;
     hipEvent_t ev_batch[kRing];
     for (int i = 0; i < kRing; ++i) SSRS_HIP_CHECK(hipEventCreate(&ev_batch[i]));
     std::vector<hipEvent_t> ev_prof, ev_bin, ev_hist;   // launch starts / ends; binning kernel brackets
