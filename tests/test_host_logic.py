@@ -116,3 +116,25 @@ def test_product_never_imports_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not pat.search(text), f'{f} imports the oracle'
                 assert 'liboracle' not in text, f'{f} references the oracle library'
+
+
+def test_tools_never_import_oracle():
+    """Development scripts that need the oracle live under tests/dev; tools/ is product-side."""
+    import os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools')
+    pat = re.compile(r'^\s*(from|import)\s+oracle\b', re.M)
+    for f in os.listdir(root):
+        if f.endswith('.py'):
+            assert not pat.search(open(os.path.join(root, f)).read()), f'tools/{f} imports the oracle'
+
+
+def test_ring_table_applies_only_to_the_reference_default_model():
+    from ssrs_amd.movmodel import ring_table_applies
+    assert ring_table_applies(1, 1.0, False, False, 0)
+    assert ring_table_applies(1, 1.0, False, False, 64)
+    assert not ring_table_applies(2, 1.0, False, False, 0)       # longer direction memory
+    assert not ring_table_applies(0, 1.0, False, False, 0)       # whole-history restriction
+    assert not ring_table_applies(1, 0.5, False, False, 0)       # nu != 1 needs pow()
+    assert not ring_table_applies(1, 1.0, True, False, 0)        # trajectories: generic kernel
+    assert not ring_table_applies(1, 1.0, False, True, 0)        # exact-only A/B
+    assert not ring_table_applies(1, 1.0, False, False, 7)       # odd steps per launch
