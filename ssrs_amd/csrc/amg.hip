@@ -340,6 +340,59 @@ __global__ __launch_bounds__(kBlock) void k_jacobi_first(const double *__restric
         x[i] = kOmega * dinv[i] * b[i];
 }
 
+// Four lanes per row for the large CSR levels: a thread-per-row walk reads val/col
+// with a stride of one row (~12 entries) between lanes; four lanes read four
+// consecutive entries, and the partial sums meet in a fixed shuffle tree
+// (reproducible).  Level 1 at 5000 x 6000: 1.15 ms -> see profiles/r01_notes.md.
+constexpr int kRowLanes = 4;
+__device__ __forceinline__ double row_dot4(const int *__restrict__ rowptr, const int *__restrict__ col,
+                                           const double *__restrict__ val, const double *__restrict__ x,
+                                           int row, int sub)
+{
+    double ax = 0.0;
+    const int end = rowptr[row + 1];
+    for (int p = rowptr[row] + sub; p < end; p += kRowLanes) ax += val[p] * x[col[p]];
+    ax += __shfl_xor(ax, 1);
+    ax += __shfl_xor(ax, 2);
+    return ax;
+}
+
+__global__ __launch_bounds__(kBlock) void k_jacobi4(const int *__restrict__ rowptr,
+                                                   const int *__restrict__ col,
+                                                   const double *__restrict__ val,
+                                                   const double *__restrict__ dinv,
+                                                   const double *__restrict__ b,
+                                                   const double *__restrict__ x, int n,
+                                                   double *__restrict__ xn)
+{
+    const int sub = threadIdx.x % kRowLanes;
+    const long long stride = static_cast<long long>(gridDim.x) * (kBlock / kRowLanes);
+    // whole groups stay in the loop together (the bound is per group, not per lane)
+    for (long long i = blockIdx.x * static_cast<long long>(kBlock / kRowLanes) + threadIdx.x / kRowLanes; i < n;
+         i += stride) {
+        const int row = static_cast<int>(i);
+        const double ax = row_dot4(rowptr, col, val, x, row, sub);
+        if (sub == 0) xn[row] = x[row] + kOmega * dinv[row] * (b[row] - ax);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_residual4(const int *__restrict__ rowptr,
+                                                     const int *__restrict__ col,
+                                                     const double *__restrict__ val,
+                                                     const double *__restrict__ b,
+                                                     const double *__restrict__ x, int n,
+                                                     double *__restrict__ r)
+{
+    const int sub = threadIdx.x % kRowLanes;
+    const long long stride = static_cast<long long>(gridDim.x) * (kBlock / kRowLanes);
+    for (long long i = blockIdx.x * static_cast<long long>(kBlock / kRowLanes) + threadIdx.x / kRowLanes; i < n;
+         i += stride) {
+        const int row = static_cast<int>(i);
+        const double ax = row_dot4(rowptr, col, val, x, row, sub);
+        if (sub == 0) r[row] = b[row] - ax;
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_jacobi(const int *__restrict__ rowptr,
                                                   const int *__restrict__ col,
                                                   const double *__restrict__ val,
@@ -846,6 +899,8 @@ int amg_setup(AmgHierarchy &h, const double *cond, const uint8_t *fixed, int row
 
 static void solve_level(AmgHierarchy &h, size_t lev, hipStream_t st);
 
+constexpr int kVectorRows = 1 << 17;     // levels at least this large use four lanes per row
+
 static void launch_jacobi(AmgHierarchy &h, size_t lev, const double *x, double *xn, hipStream_t st)
 {
     AmgLevel &L = h.levels[lev];
@@ -853,7 +908,11 @@ static void launch_jacobi(AmgHierarchy &h, size_t lev, const double *x, double *
         const L0Stencil a{h.l0_rinv, h.l0_fixed, h.l0_rows, h.l0_cols};
         hipLaunchKernelGGL(k_l0_jacobi, dim3(grid_for(L.n)), dim3(kBlock), 0, st, a, L.dinv, L.b, x, xn);
     } else {
-        hipLaunchKernelGGL(k_jacobi, dim3(grid_for(L.n)), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.dinv, L.b, x, L.n, xn);
+        if (L.n >= kVectorRows)
+            hipLaunchKernelGGL(k_jacobi4, dim3(grid_for(static_cast<size_t>(L.n) * kRowLanes)), dim3(kBlock), 0, st,
+                               L.rowptr, L.col, L.val, L.dinv, L.b, x, L.n, xn);
+        else
+            hipLaunchKernelGGL(k_jacobi, dim3(grid_for(L.n)), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.dinv, L.b, x, L.n, xn);
     }
 }
 
@@ -864,7 +923,11 @@ static void launch_residual(AmgHierarchy &h, size_t lev, hipStream_t st)
         const L0Stencil a{h.l0_rinv, h.l0_fixed, h.l0_rows, h.l0_cols};
         hipLaunchKernelGGL(k_l0_residual, dim3(grid_for(L.n)), dim3(kBlock), 0, st, a, L.b, L.x, L.r);
     } else {
-        hipLaunchKernelGGL(k_residual, dim3(grid_for(L.n)), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.b, L.x, L.n, L.r);
+        if (L.n >= kVectorRows)
+            hipLaunchKernelGGL(k_residual4, dim3(grid_for(static_cast<size_t>(L.n) * kRowLanes)), dim3(kBlock), 0, st,
+                               L.rowptr, L.col, L.val, L.b, L.x, L.n, L.r);
+        else
+            hipLaunchKernelGGL(k_residual, dim3(grid_for(L.n)), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.b, L.x, L.n, L.r);
     }
 }
 
