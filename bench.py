@@ -52,6 +52,8 @@ def parse():
     ap.add_argument('--no-schedule', action='store_true', help='disable the coherent schedule')
     ap.add_argument('--exact-only', action='store_true', help='disable the fast decision path')
     ap.add_argument('--f64-table', action='store_true', help='8 x f64 transition table instead of the f32 ring table')
+    ap.add_argument('--dem-noise', type=float, default=1.5,
+                    help='sigma of the per-cell DEM noise in metres (SURVEY 8(d) prescribes 1.5 at every resolution)')
     return ap.parse_args()
 
 
@@ -127,7 +129,7 @@ def main():
     seed = 30
     n_total = args.tracks * world
     # identical on every rank: replicated rasters, global start list
-    dem_h = synthetic_dem(gridsize, res)
+    dem_h = synthetic_dem(gridsize, res, noise=args.dem_noise)
     np.random.seed(seed)
     srows, scols = movmodel.get_starting_indices(n_total, (5, 55, 1, 2), 'random',
                                                  tuple(args.width_km), res)
@@ -254,7 +256,8 @@ def main():
         'config': {
             'workload': (f'uniform mode, {args.width_km[0]:g}x{args.width_km[1]:g} km @{res:g} m '
                          f'({rows}x{cols} grid), {args.tracks} tracks per GPU, wind 10 m/s @270, '
-                         f'threshold 0.75, direction 0, seed 30 (BASELINE.json configs[1])'),
+                         f'threshold 0.75, direction 0, seed 30 (BASELINE.json configs[1])'
+                         + ('' if args.dem_noise == 1.5 else f', DEM noise sigma {args.dem_noise:g} m')),
             'tracks_total': n_total,
             'parallelism': f'track-sharded x{world}, replicated rasters'
                            + (f', {"RCCL" if backend == "nccl" else backend} histogram reduce (async, under the next step)'
