@@ -152,7 +152,7 @@ static_assert(ring_order(0) == (0u | (1u << 2) | (2u << 4)), "after N: NW, N, NE
 static_assert(ring_order(2) == (2u | (1u << 2) | (0u << 4)), "after E: NE, E, SE are k = 8, 5, 2");
 constexpr uint32_t pack_ring_deltas(bool rows)
 {
-    uint32_t v = 0;
+    uint32_t v = 1u << 16;                                    // ring 8 = the centre: no displacement
     for (int c = 0; c < 8; ++c)
         v |= static_cast<uint32_t>((rows ? dr_of(kRingK[c]) : dc_of(kRingK[c])) + 1) << (2 * c);
     return v;
@@ -475,11 +475,20 @@ __global__ __launch_bounds__(kBlock) void k_transition_table(
 #pragma unroll
         for (int j = 0; j < 9; ++j) has_nan |= (w[j] != w[j]);
         if (RING) {
+            // a weight that is EXACTLY zero after the clip is stored as -0.0f (the sign bit is
+            // free: weights are >= 0), so the stepper can tell "all three admissible weights
+            // are zero" (-> the reference's fallback to the directional prior, common in
+            // real potential fields) from positive weights below the f32 range (+0.0f).
+            // Rows with an infinite weight are poisoned like NaN rows: the prior shortcut
+            // relies on masked-out weights times 0.0 being 0.0 (movmodel.py:231).
+            bool bad = has_nan;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) bad |= (w[j] - w[j] != 0.0);     // inf or NaN
             float f[kRingFloats];
 #pragma unroll
             for (int j = 0; j < kRingFloats; ++j) {
                 const double v = w[kRingK[(j + 7) % 8]];
-                f[j] = static_cast<float>(has_nan ? __builtin_nan("") : (v > 0.0 ? v : 0.0));
+                f[j] = bad ? __builtin_nanf("") : (v > 0.0 ? static_cast<float>(v) : -0.0f);
             }
             float2 *dst = reinterpret_cast<float2 *>(static_cast<float *>(table_out) + i * kRingFloats);
 #pragma unroll
@@ -596,6 +605,7 @@ struct StepArgs {
     uint32_t *visits;            // [steps][visit_stride] visited cell per slot (K3 binning), or NULL
     long long visit_stride;
     uint32_t cap;                // slots per XCD list (multiple of kBlock); list x = [x*cap, (x+1)*cap)
+    const double *thr;           // [9][9] prior-fallback thresholds (k_prior_thresholds)
 };
 
 __global__ __launch_bounds__(kBlock) void k_tracks_init(
@@ -881,6 +891,42 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
     if (lane == 0 && m) atomicAdd(&ctl->steps, m);
 }
 
+// Decision thresholds of the prior fallback (movmodel.py:234-244): when every admissible
+// weight is exactly zero the move distribution depends on (prior, last move) only.
+// thr[d * 9 + k] = cdf_k / cdf_8 for last move d, computed with the arithmetic of
+// choose_move's exact branch (same pairwise sums, same divisions), so that
+// "count of thr <= u" IS np.random.choice's pick.
+__global__ void k_prior_thresholds(const double *__restrict__ prior, double *__restrict__ thr)
+{
+    const int d = threadIdx.x;
+    if (d >= 9) return;
+    const uint32_t mask = restriction_of(static_cast<uint32_t>(d));
+    double q[9];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        q[k] = ((mask >> k) & 1u) && k != 4 ? prior[k] : 0.0;
+        any |= (q[k] != 0.0);
+    }
+    if (!any) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) q[k] = prior[k];
+    }
+    const double s1 = sum9(q);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) q[k] = q[k] / s1;
+    const double s2 = sum9(q);
+    double acc = 0.0, cdf[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        q[k] = q[k] / s2;
+        acc = acc + q[k];
+        cdf[k] = acc;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) thr[d * 9 + k] = cdf[k] / cdf[8];
+}
+
 // ---------------------------------------------------------------- lean stepper
 // The production configuration (table, memory_parameter 1, nu = 1, no trajectory
 // output, even S) written flat: a step is bound by its chain of dependent
@@ -1014,16 +1060,30 @@ __global__ __launch_bounds__(kBlock) void k_step_lean(const StepArgs a)
             int sel = choose_three_ring_f32(__uint_as_float(ba), __uint_as_float(bb), __uint_as_float(bc), uf);
             bool slow = st && (sel < 0 || rc == 8u);
             double u = 0.0;
+            uint32_t prior_nc = 8u;
             if (__builtin_expect(__any(slow), 0)) {
-                // second tier: f64 sums and the full 53-bit u (band 2^-21)
                 u = words_to_uniform(w0, w1);
-                if (slow) {
-                    sel = choose_three_ring(__uint_as_float(ba), __uint_as_float(bb), __uint_as_float(bc), u);
-                    slow = sel < 0 || rc == 8u;
+                if (slow && rc != 8u) {
+                    if ((ba & bb & bc) == 0x80000000u && (ba | bb | bc) == 0x80000000u) {
+                        // all three admissible weights are exactly zero: the directional
+                        // prior decides (movmodel.py:234-240); thresholds precomputed per
+                        // last move with the exact arithmetic (k_prior_thresholds)
+                        const double *t = a.thr + 9u * (static_cast<uint32_t>(kKOfRing >> (4 * rc)) & 0xFu);
+                        int idx = 0;
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) idx += t[k] <= u ? 1 : 0;
+                        prior_nc = static_cast<uint32_t>(kRingOfK >> (4 * idx)) & 0xFu;
+                        slow = prior_nc >= 8u;      // a pick of the centre (unmasked prior): exact path
+                    } else {
+                        // second tier: f64 sums and the full 53-bit u (band 2^-21)
+                        sel = choose_three_ring(__uint_as_float(ba), __uint_as_float(bb), __uint_as_float(bc), u);
+                        slow = sel < 0;
+                    }
                 }
             }
             // ring position of the chosen cell: rc - 1 + (which x it was)
             uint32_t nc = (rc + 7u + ((ord >> (2 * (sel < 0 ? 0 : sel))) & 3u)) & 7u;
+            nc = prior_nc < 8u ? prior_nc : nc;
             if (__builtin_expect(__any(slow), 0)) {
                 if (slow) {
                     // first step of a track (8 admissible cells), near-ties, poisoned rows:
@@ -1241,6 +1301,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Workspace {
     TrackCtl *ctl;
+    double *thr;
     TrackState *state;
     int32_t *list[2];
     unsigned long long *keys[2];
@@ -1272,6 +1333,8 @@ static size_t workspace_layout(int64_t n, char *base, Workspace *ws)
     if (ws) ws->cap = static_cast<uint32_t>(cap);
     if (ws) ws->ctl = reinterpret_cast<TrackCtl *>(base + off);
     off = align_up(off + sizeof(TrackCtl), 256);
+    if (ws) ws->thr = reinterpret_cast<double *>(base + off);
+    off = align_up(off + 81 * sizeof(double), 256);
     if (ws) ws->state = reinterpret_cast<TrackState *>(base + off);
     off = align_up(off + sizeof(TrackState) * static_cast<size_t>(n), 256);
     for (int i = 0; i < 2; ++i) {
@@ -1474,6 +1537,8 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
     a.fast = ((p->flags & SSRS_TRACKS_EXACT_ONLY) == 0 && p->scaling_parameter == 1.0) ? 1 : 0;
     a.coherent = coherent ? 1 : 0;
     a.cap = ws.cap;
+    a.thr = ws.thr;
+    hipLaunchKernelGGL(k_prior_thresholds, dim3(1), dim3(64), 0, st, ws.ctl->prior, ws.thr);
     const bool lean = p->memory_parameter == 1 && traj == nullptr;
     const bool ring = (p->flags & SSRS_TRACKS_RING_TABLE) != 0;
     if (ring)
