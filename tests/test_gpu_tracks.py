@@ -442,3 +442,26 @@ def test_ring_table_large_batch_equals_f64_table(gpu):
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
     assert int(b[2].sum()) == int(b[0].sum())
+
+
+@pytest.mark.parametrize('rows,cols,n,dirn', [(5, 5, 3, 0.), (6, 40, 65, 90.), (33, 7, 129, 200.),
+                                              (64, 31000, 300, 0.), (257, 263, 9000, 315.)])
+def test_odd_shapes_all_paths_agree_with_oracle(gpu, rows, cols, n, dirn):
+    """Smallest legal raster, single waves, rasters wider than the binning window,
+    batches on both sides of the binning threshold: ring table, f64 table and window
+    gathers all equal the oracle."""
+    from ssrs_amd import movmodel
+    from oracle import c_oracle
+    rng = np.random.default_rng(rows * 1000 + cols)
+    upd = np.abs(rng.normal(0.8, 0.6, (rows, cols)))
+    upd[rng.random((rows, cols)) < 0.3] = 0.0                     # dead cells
+    pot = (1000. * (1 - np.arange(rows)[:, None] / max(rows - 1., 1.)) +
+           rng.normal(0, 2.0, (rows, cols))).astype(np.float32)
+    starts = np.stack([rng.integers(0, rows, n), rng.integers(0, cols, n)], 1)
+    ref = c_oracle.simulate_tracks(dirn, starts, (rows, cols), 1, 1., upd, pot, seed=5, want_traj=False)
+    for kw in (dict(use_table=True, ring=True), dict(use_table=True, ring=False), dict(use_table=False)):
+        res = movmodel.simulate_tracks(dirn, starts, (rows, cols), 1, 1., upd, pot, seed=5, **kw)
+        lens, ends, hist = _no_traj_result(res)
+        assert np.array_equal(lens, ref['lengths']), kw
+        assert np.array_equal(ends, ref['ends']), kw
+        assert np.array_equal(hist, ref['hist']), kw
