@@ -146,6 +146,14 @@ typedef struct SsrsTrackParams {
                                     needs updraft (+ potential if the table was built with it)
                                     for the exact decision of near-ties, memory_parameter 1,
                                     scaling_parameter 1, traj NULL, even steps_per_launch */
+#define SSRS_TRACKS_SCATTERED 32    /* treat the batch as scattered from the first launch: the
+                                      histogram is counted by the de-duplicating per-track kernel
+                                      (tracks that circle in a pocket of the field cost a few
+                                      atomics per launch, not one per step) and the ring stepper
+                                      reads the per-cell zero-mask byte before gathering.  Default:
+                                      switched on when the batch stops moving as a front.  Results
+                                      are identical */
+#define SSRS_TRACKS_NO_SCATTERED 64 /* never switch to that variant (A/B) */
 #define SSRS_TRACKS_EXACT_ONLY 2 /* disable the guarded division-free decision
                                    (A/B switch; results are identical) */
 
@@ -175,13 +183,21 @@ int ssrs_transition_table_build(const double *updraft, const float *potential,
  * a move only the three cells within +-45 deg are admissible (movmodel.py:185-202),
  * and in clockwise ring order N, NE, E, SE, S, SW, W, NW they are consecutive.  Per
  * cell 10 f32 = the ring-ordered weights rounded to f32, stored as ring 7, 0, 1, ...,
- * 7, 0 (40 B).  ring: ssrs_transition_ring_bytes(rows, cols) bytes, 8-byte aligned. */
+ * 7, 0 (40 B), exact zeros as -0.0f; behind the records one zero-mask byte per cell (bit c:
+ * ring weight c is exactly zero).  ring: ssrs_transition_ring_bytes(rows, cols) bytes,
+ * 8-byte aligned. */
 size_t ssrs_transition_ring_bytes(int rows, int cols);
 int ssrs_transition_ring_build(const double *updraft, const float *potential, float *ring,
                                int rows, int cols, void *stream);
 
 /* Bytes of device scratch ssrs_tracks_simulate needs for `ntracks`. */
 size_t ssrs_tracks_workspace_bytes(int64_t ntracks);
+/* The same plus room for `hist_copies` (2..64) private copies of the histogram.  A
+ * workspace of this size lets ssrs_tracks_simulate privatise the histogram once a batch
+ * is scattered (many tracks circling in the same pockets of a real potential field make
+ * per-step atomics on single cells queue up at the memory side: 3x slower); the copies
+ * are added to `hist` before the call returns.  Optional: the smaller workspace works. */
+size_t ssrs_tracks_workspace_bytes_ex(int64_t ntracks, int rows, int cols, int hist_copies);
 
 /* generate_simulated_tracks for a batch of tracks (movmodel.py:264-318, driven
  * as Simulator.simulate_tracks does, simulator.py:360-369) + the histogram of

@@ -17,6 +17,8 @@ SSRS_TRACKS_EXACT_ONLY = 2
 SSRS_TRACKS_NO_SCHEDULE = 4
 SSRS_TRACKS_NO_BINNING = 8
 SSRS_TRACKS_RING_TABLE = 16
+SSRS_TRACKS_SCATTERED = 32
+SSRS_TRACKS_NO_SCATTERED = 64
 SSRS_SOLVE_NO_AMG = 1
 
 EXPORTS = (
@@ -25,7 +27,7 @@ EXPORTS = (
     'ssrs_wind_from_lattice', 'ssrs_thermal_seeds', 'ssrs_blur_workspace_bytes',
     'ssrs_gaussian_blur', 'ssrs_track_params_init', 'ssrs_transition_table_build',
     'ssrs_transition_ring_bytes', 'ssrs_transition_ring_build',
-    'ssrs_tracks_workspace_bytes', 'ssrs_tracks_simulate', 'ssrs_uniform_selftest',
+    'ssrs_tracks_workspace_bytes', 'ssrs_tracks_workspace_bytes_ex', 'ssrs_tracks_simulate', 'ssrs_uniform_selftest',
     'ssrs_presence_count', 'ssrs_presence_workspace_bytes', 'ssrs_presence_smooth',
     'ssrs_presence_normalise_add', 'ssrs_presence_normalise_f32',
     'ssrs_potential_workspace_bytes', 'ssrs_potential_solve',
@@ -72,6 +74,8 @@ def lib():
         L.ssrs_last_error.restype = C.c_char_p
         L.ssrs_tracks_workspace_bytes.restype = C.c_size_t
         L.ssrs_tracks_workspace_bytes.argtypes = [C.c_int64]
+        L.ssrs_tracks_workspace_bytes_ex.restype = C.c_size_t
+        L.ssrs_tracks_workspace_bytes_ex.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int]
         L.ssrs_transition_ring_bytes.restype = C.c_size_t
         L.ssrs_transition_ring_bytes.argtypes = [C.c_int, C.c_int]
         if hasattr(L, 'ssrs_presence_workspace_bytes'):

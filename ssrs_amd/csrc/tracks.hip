@@ -173,6 +173,11 @@ constexpr uint64_t pack_k_of_ring()
 }
 constexpr uint64_t kKOfRing = pack_k_of_ring();
 constexpr int kRingFloats = 10;                               // ring 7, 0, 1, ..., 7, 0 per cell
+// ring table buffer = records, 8 bytes of slack for the last 12-byte load, zero-mask bytes
+__host__ __device__ constexpr size_t ring_mask_offset(int rows, int cols)
+{
+    return static_cast<size_t>(rows) * static_cast<size_t>(cols) * kRingFloats * sizeof(float) + 8;
+}
 
 // ------------------------------------------------------------------- uniform
 // rocRAND Philox4x32-10: key = seed, counter = (blk, track); one 4-word block
@@ -493,6 +498,12 @@ __global__ __launch_bounds__(kBlock) void k_transition_table(
             float2 *dst = reinterpret_cast<float2 *>(static_cast<float *>(table_out) + i * kRingFloats);
 #pragma unroll
             for (int k = 0; k < kRingFloats / 2; ++k) dst[k] = make_float2(f[2 * k], f[2 * k + 1]);
+            // zero mask (one byte per cell behind the records): bit c = ring weight c is exactly
+            // zero.  Tracks that wander through dead terrain read only this byte per step.
+            uint32_t zm = 0;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) zm |= (!bad && !(w[kRingK[c]] > 0.0)) ? (1u << c) : 0u;
+            (static_cast<uint8_t *>(table_out) + ring_mask_offset(rows, cols))[i] = static_cast<uint8_t>(zm);
         } else {
             double2 *dst = reinterpret_cast<double2 *>(static_cast<double *>(table_out) + i * 8);
             double o[8];
@@ -606,6 +617,9 @@ struct StepArgs {
     long long visit_stride;
     uint32_t cap;                // slots per XCD list (multiple of kBlock); list x = [x*cap, (x+1)*cap)
     const double *thr;           // [9][9] prior-fallback thresholds (k_prior_thresholds)
+    const uint8_t *zmask;        // ring table's zero-mask bytes (scattered variant), or NULL
+    uint32_t *hist_copies;       // privatised histogram copies (scattered batches), or NULL
+    int ncopies;
 };
 
 __global__ __launch_bounds__(kBlock) void k_tracks_init(
@@ -858,7 +872,11 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
             a.visits[static_cast<long long>(it) * a.visit_stride + i] =
                 stepped ? static_cast<uint32_t>(row) * a.cols + col : 0xFFFFFFFFu;
         } else if (a.hist) {
-            atomicAdd(&a.hist[static_cast<size_t>(row) * a.cols + col], stepped ? 1u : 0u);
+            uint32_t *h = a.hist;
+            if (a.hist_copies)
+                h = a.hist_copies + static_cast<size_t>((i >> 6) % static_cast<uint32_t>(a.ncopies)) *
+                                        (static_cast<size_t>(a.rows) * a.cols);
+            atomicAdd(&h[static_cast<size_t>(row) * a.cols + col], stepped ? 1u : 0u);
         }
         last_it = it;
     }
@@ -961,7 +979,14 @@ struct __attribute__((packed, aligned(4))) RingTriple { float x0, x1, x2; };
 // address unit ~64 cycles whatever its width: with 6 waves per CU the three
 // gathers were half of a step's time); near-ties are decided by the exact
 // sequence on the raw 3x3 windows of updraft / potential.
-template <bool RING>
+// ZMASK (ring table only; chosen by the host once a batch no longer moves as a front):
+// with real potential fields most steps of a long track happen in dead terrain where all
+// three admissible weights are exactly zero and the prior decides.  The 12-byte gather
+// of such a step is a random HBM access that only delivers three zeros; the cell's
+// zero-mask byte says the same, and a wandering track reuses its 128-cell line for many
+// steps.  Lanes whose mask bits are not all set gather as usual (one more dependent
+// load, which is why the front-shaped regime does not use this variant).
+template <bool RING, bool ZMASK = false>
 __global__ __launch_bounds__(kBlock) void k_step_lean(const StepArgs a)
 {
     TrackCtl *ctl = a.ctl;
@@ -1019,7 +1044,14 @@ __global__ __launch_bounds__(kBlock) void k_step_lean(const StepArgs a)
             // triple (ring rc-1, rc, rc+1) = floats rc .. rc+2 of the cell's record
             const float *src = reinterpret_cast<const float *>(a.table) +
                                static_cast<size_t>(cell) * kRingFloats + (rc & 7u);
-            x = *reinterpret_cast<const RingTriple *>(src);
+            if (ZMASK) {
+                const uint32_t m = a.zmask[cell];
+                const uint32_t tri = (((m << 8) | m) >> ((rc + 7u) & 7u)) & 7u;   // bits rc-1, rc, rc+1
+                if (tri == 7u && rc != 8u) x = RingTriple{-0.0f, -0.0f, -0.0f};
+                else x = *reinterpret_cast<const RingTriple *>(src);
+            } else {
+                x = *reinterpret_cast<const RingTriple *>(src);
+            }
         } else {
             cand = candidates_of(dirs & 0xFu);
             const double *src = a.table + static_cast<size_t>(cell) * 8;
@@ -1143,7 +1175,13 @@ __global__ __launch_bounds__(kBlock) void k_step_lean(const StepArgs a)
         if (a.visits) {
             a.visits[static_cast<long long>(it) * a.visit_stride + i] = st ? cell : 0xFFFFFFFFu;
         } else if (a.hist) {
-            atomicAdd(&a.hist[cell], st ? 1u : 0u);
+            uint32_t *h = a.hist;
+            // scattered variant: wave-private copy, so that same-address atomics of
+            // different waves do not queue up (compiled out of the front-shaped variant)
+            if ((ZMASK || !RING) && a.hist_copies)
+                h = a.hist_copies + static_cast<size_t>((i >> 6) % static_cast<uint32_t>(a.ncopies)) *
+                                        (static_cast<size_t>(a.rows) * ucols);
+            atomicAdd(&h[cell], st ? 1u : 0u);
         }
         last_it = it;
     };
@@ -1297,6 +1335,27 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_visits(const uint32_t *__re
     }
 }
 
+// K3 for batches that no longer move as a front.  With real potential fields long
+// tracks circle in pockets of the field, many tracks in the same pockets: 9e9 visits fell
+// on 1.3e7 distinct cells (one cell: 4.6e7) in a C2 run, and the per-step global atomics
+// -- same address, hence serialised at the memory side -- made the stepper seven times
+// slower than without a histogram (a track itself revisits little: 353 distinct cells
+// per 512 steps, so per-track de-duplication was measured and gained nothing).  What
+// helps is privatisation: wave w counts into copy w mod K of the histogram (K copies
+// in the caller's workspace when it is large enough, ssrs_tracks_workspace_bytes_ex);
+// the copies are added to `hist` once at the end.  5.8 -> 14 (K = 16) / 17.5 (K = 64)
+// G steps/s on the C2 run.
+__global__ __launch_bounds__(kBlock) void k_fold_copies(const uint32_t *__restrict__ copies, int ncopies,
+                                                       size_t ncell, uint32_t *__restrict__ hist)
+{
+    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < ncell;
+         i += static_cast<size_t>(gridDim.x) * kBlock) {
+        uint32_t s = 0;
+        for (int c = 0; c < ncopies; ++c) s += copies[static_cast<size_t>(c) * ncell + i];
+        if (s) hist[i] += s;
+    }
+}
+
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Workspace {
@@ -1399,6 +1458,14 @@ extern "C" size_t ssrs_tracks_workspace_bytes(int64_t ntracks)
     return workspace_layout(ntracks, nullptr, nullptr);
 }
 
+extern "C" size_t ssrs_tracks_workspace_bytes_ex(int64_t ntracks, int rows, int cols, int hist_copies)
+{
+    const size_t base = align_up(ssrs_tracks_workspace_bytes(ntracks), 256);
+    if (rows <= 0 || cols <= 0 || hist_copies < 2) return base;
+    if (hist_copies > 64) hist_copies = 64;
+    return base + static_cast<size_t>(hist_copies) * static_cast<size_t>(rows) * static_cast<size_t>(cols) * sizeof(uint32_t);
+}
+
 extern "C" int ssrs_transition_table_build(const double *updraft, const float *potential,
                                            double *table, int rows, int cols, void *stream)
 {
@@ -1416,8 +1483,10 @@ extern "C" int ssrs_transition_table_build(const double *updraft, const float *p
 extern "C" size_t ssrs_transition_ring_bytes(int rows, int cols)
 {
     if (rows <= 0 || cols <= 0) return 0;
-    // + 8 bytes: the 12-byte load of the last cell's last triple stays inside the buffer
-    return static_cast<size_t>(rows) * static_cast<size_t>(cols) * kRingFloats * sizeof(float) + 8;
+    // records + 8 bytes (the 12-byte load of the last cell's last triple stays inside the
+    // buffer) + one zero-mask byte per cell, rounded to whole floats
+    const size_t cells = static_cast<size_t>(rows) * static_cast<size_t>(cols);
+    return ring_mask_offset(rows, cols) + (cells + 3) / 4 * 4;
 }
 
 extern "C" int ssrs_transition_ring_build(const double *updraft, const float *potential,
@@ -1558,6 +1627,22 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
     a.visits = nullptr;
     a.visit_stride = ws.visit_stride;
     bool binning_on = binning && ntracks >= 8192;   // small batches: plain atomics are cheaper
+    // SSRS_TRACKS_SCATTERED forces the zero-mask variant from the first launch,
+    // SSRS_TRACKS_NO_SCATTERED keeps it off (A/B switches; results are identical)
+    const bool never_scattered = (p->flags & SSRS_TRACKS_NO_SCATTERED) != 0;
+    bool scattered = (p->flags & SSRS_TRACKS_SCATTERED) != 0;
+    if (scattered) binning_on = false;
+    // private histogram copies live behind the regular workspace when the caller gave room
+    const size_t ncell = static_cast<size_t>(p->rows) * static_cast<size_t>(p->cols);
+    const size_t ws_base = align_up(ssrs_tracks_workspace_bytes(ntracks), 256);
+    int ncopies = 0;
+    if (hist && workspace_bytes > ws_base) ncopies = static_cast<int>((workspace_bytes - ws_base) / (ncell * sizeof(uint32_t)));
+    ncopies = ncopies > 64 ? 64 : ncopies;
+    uint32_t *copies_ptr = ncopies >= 2 ? reinterpret_cast<uint32_t *>(static_cast<char *>(workspace) + ws_base) : nullptr;
+    bool copies_live = false;
+    a.hist_copies = nullptr;
+    a.ncopies = 1;
+    a.zmask = ring ? reinterpret_cast<const uint8_t *>(table) + ring_mask_offset(p->rows, p->cols) : nullptr;
     unsigned long long seen_steps = 0, seen_strays = 0;
     hipEvent_t ev_step[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     bool done_valid[2] = {false, false};
@@ -1590,6 +1675,16 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
             const unsigned blocks = kXcd * ((upper + kBlock - 1) / kBlock);
             const int vb = launch & 1;
             a.visits = nullptr;
+            if (!binning_on && scattered && copies_ptr && !copies_live) {
+                // first scattered launch: zero the private copies, count into them from now on
+                if (hipMemsetAsync(copies_ptr, 0, sizeof(uint32_t) * ncell * ncopies, st) != hipSuccess) {
+                    rc = set_error(SSRS_ERR_HIP, "histogram copies memset failed");
+                    break;
+                }
+                copies_live = true;
+                a.hist_copies = copies_ptr;
+                a.ncopies = ncopies;
+            }
             if (binning_on) {
                 a.visits = ws.visits[vb];
                 if (kOverlapBinning && done_valid[vb]) (void)hipStreamWaitEvent(st, ev_done[vb], 0);   // buffer free again
@@ -1600,8 +1695,9 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
             }
             switch (mode) {
             case MODE_TABLE:
-                if (ring) hipLaunchKernelGGL(k_step_lean<true>, dim3(blocks), dim3(kBlock), 0, st, a);
-                else if (lean && a.fast && (S & 1) == 0) hipLaunchKernelGGL(k_step_lean<false>, dim3(blocks), dim3(kBlock), 0, st, a);
+                if (ring && scattered && !binning_on) hipLaunchKernelGGL((k_step_lean<true, true>), dim3(blocks), dim3(kBlock), 0, st, a);
+                else if (ring) hipLaunchKernelGGL((k_step_lean<true, false>), dim3(blocks), dim3(kBlock), 0, st, a);
+                else if (lean && a.fast && (S & 1) == 0) hipLaunchKernelGGL((k_step_lean<false, false>), dim3(blocks), dim3(kBlock), 0, st, a);
                 else if (lean) hipLaunchKernelGGL((k_step_tracks<MODE_TABLE, true>), dim3(blocks), dim3(kBlock), 0, st, a);
                 else hipLaunchKernelGGL((k_step_tracks<MODE_TABLE, false>), dim3(blocks), dim3(kBlock), 0, st, a);
                 break;
@@ -1665,7 +1761,10 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
             // to in-stepper atomics
             if (binning_on) {
                 const unsigned long long dsteps = tot[0] - seen_steps, dstray = tot[1] - seen_strays;
-                if (dsteps > 0 && dstray * 4 > dsteps) binning_on = false;
+                if (dsteps > 0 && dstray * 4 > dsteps) {
+                    binning_on = false;
+                    scattered = !never_scattered;          // no front any more: zero-mask variant
+                }
             }
             seen_steps = tot[0];
             seen_strays = tot[1];
@@ -1674,6 +1773,8 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
     if (binning)
         for (int i = 0; i < 2; ++i)
             if (done_valid[i]) (void)hipStreamWaitEvent(st, ev_done[i], 0);    // histogram complete on `stream`
+    if (copies_live && rc == SSRS_OK)
+        hipLaunchKernelGGL(k_fold_copies, dim3(4096), dim3(kBlock), 0, st, copies_ptr, ncopies, ncell, hist);
     if (profile) {
         hipEvent_t e;
         if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); ev_prof.push_back(e); }

@@ -76,7 +76,7 @@ def get_directional_probs(theta):
 
 def make_track_params(grid_shape, move_dirn, memory_parameter=1, scaling_parameter=1.,
                       steps_per_launch=0, profile=False, exact_only=False, schedule=True,
-                      binning=True, ring=False):
+                      binning=True, ring=False, scattered=None):
     rows, cols = int(grid_shape[0]), int(grid_shape[1])
     p = nat.SsrsTrackParams()
     nat.check(nat.lib().ssrs_track_params_init(C.byref(p), rows, cols, int(memory_parameter),
@@ -89,7 +89,8 @@ def make_track_params(grid_shape, move_dirn, memory_parameter=1, scaling_paramet
         (nat.SSRS_TRACKS_EXACT_ONLY if exact_only else 0) | \
         (0 if schedule else nat.SSRS_TRACKS_NO_SCHEDULE) | \
         (0 if binning else nat.SSRS_TRACKS_NO_BINNING) | \
-        (nat.SSRS_TRACKS_RING_TABLE if ring else 0)
+        (nat.SSRS_TRACKS_RING_TABLE if ring else 0) | \
+        (0 if scattered is None else (nat.SSRS_TRACKS_SCATTERED if scattered else nat.SSRS_TRACKS_NO_SCATTERED))
     return p
 
 
@@ -144,7 +145,8 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
                     scaling_parameter=1., updraft_field=None, potential_field=None, *,
                     seed=0, track_id_base=0, table=None, use_table=None, hist=None,
                     want_hist=True, want_tracks=False, steps_per_launch=0, profile=False,
-                    exact_only=False, schedule=True, binning=True, ring=None):
+                    exact_only=False, schedule=True, binning=True, ring=None, scattered=None,
+                    max_moves=None):
     """generate_simulated_tracks for a whole batch (movmodel.py:264-318 under
     simulator.py:360-369) + presence histogram (movmodel.py:410-419).
 
@@ -184,12 +186,21 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
         raise ValueError('the ring table needs memory_parameter 1, scaling_parameter 1, no '
                          'trajectory output, exact_only=False and an even steps_per_launch')
     p = make_track_params((rows, cols), move_dirn, memory_parameter, scaling_parameter,
-                          steps_per_launch, profile, exact_only, schedule, binning, ring=is_ring)
+                          steps_per_launch, profile, exact_only, schedule, binning, ring=is_ring,
+                          scattered=scattered)
+    if max_moves is not None:          # probe hook: cap below the reference's R/2 * C/2 (movmodel.py:277)
+        p.max_moves = int(max_moves)
     if hist is None and want_hist:
         hist = torch.zeros((rows, cols), dtype=torch.int32, device=dev)
     lengths = torch.empty(n, dtype=torch.int32, device=dev)
     ends = torch.empty((n, 2), dtype=torch.int16, device=dev)
-    ws_bytes = nat.lib().ssrs_tracks_workspace_bytes(n)
+    # room for private histogram copies (used only once a batch is scattered): up to 64,
+    # within 4 GB
+    copies = 0
+    if hist is not None:
+        copies = int(min(64, (4 << 30) // (rows * cols * 4)))
+        copies = copies if copies >= 2 else 0
+    ws_bytes = nat.lib().ssrs_tracks_workspace_bytes_ex(n, rows, cols, copies)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     stats = nat.SsrsTrackStats()
 

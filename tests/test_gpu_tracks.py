@@ -417,14 +417,14 @@ def test_ring_table_vs_c_oracle(gpu, case):
     starts = np.stack([rng.integers(0, rows, n), rng.integers(0, cols, n)], 1)
     ref = c_oracle.simulate_tracks(20., starts, (rows, cols), 1, 1., upd, pot, seed=11,
                                    track_id_base=77, want_traj=False)
-    for ring in (False, True):
+    for ring, scattered in ((False, None), (True, False), (True, True)):
         res = movmodel.simulate_tracks(20., starts, (rows, cols), 1, 1., upd, pot, seed=11,
                                        track_id_base=77, use_table=True, ring=ring,
-                                       steps_per_launch=32)
+                                       scattered=scattered, steps_per_launch=32)
         lens, ends, hist = _no_traj_result(res)
-        assert np.array_equal(lens, ref['lengths']), (case, ring)
-        assert np.array_equal(ends, ref['ends']), (case, ring)
-        assert np.array_equal(hist, ref['hist']), (case, ring)
+        assert np.array_equal(lens, ref['lengths']), (case, ring, scattered)
+        assert np.array_equal(ends, ref['ends']), (case, ring, scattered)
+        assert np.array_equal(hist, ref['hist']), (case, ring, scattered)
 
 
 def test_ring_table_large_batch_equals_f64_table(gpu):
@@ -459,7 +459,8 @@ def test_odd_shapes_all_paths_agree_with_oracle(gpu, rows, cols, n, dirn):
            rng.normal(0, 2.0, (rows, cols))).astype(np.float32)
     starts = np.stack([rng.integers(0, rows, n), rng.integers(0, cols, n)], 1)
     ref = c_oracle.simulate_tracks(dirn, starts, (rows, cols), 1, 1., upd, pot, seed=5, want_traj=False)
-    for kw in (dict(use_table=True, ring=True), dict(use_table=True, ring=False), dict(use_table=False)):
+    for kw in (dict(use_table=True, ring=True), dict(use_table=True, ring=True, scattered=True),
+               dict(use_table=True, ring=False), dict(use_table=False)):
         res = movmodel.simulate_tracks(dirn, starts, (rows, cols), 1, 1., upd, pot, seed=5, **kw)
         lens, ends, hist = _no_traj_result(res)
         assert np.array_equal(lens, ref['lengths']), kw

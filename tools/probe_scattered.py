@@ -17,7 +17,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 np.random.seed(30)
 r, c = movmodel.get_starting_indices(n, (2, 22, 1, 2), 'random', (24., 20.), 10.)
 starts = np.stack([r, c], 1)
-for kw in (dict(), dict(ring=False)):
+for kw in (dict(scattered=False), dict(scattered=True), dict(ring=False)):
     torch.cuda.synchronize(); t = time.time()
     out = movmodel.simulate_tracks(0., starts, shape, 1, 1., upd, pot, seed=30, use_table=True, profile=True, **kw)
     torch.cuda.synchronize(); dt = time.time() - t
