@@ -1766,6 +1766,11 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
                     scattered = !never_scattered;          // no front any more: zero-mask variant
                 }
             }
+            // batches that never binned (small, unsorted, very wide rasters) give no stray
+            // signal: tracks still alive after four raster crossings are wandering
+            if (!binning_on && !scattered && !never_scattered &&
+                static_cast<long long>(launch) * S > 4ll * (p->rows + p->cols))
+                scattered = true;
             seen_steps = tot[0];
             seen_strays = tot[1];
         }
