@@ -466,3 +466,22 @@ def test_odd_shapes_all_paths_agree_with_oracle(gpu, rows, cols, n, dirn):
         assert np.array_equal(lens, ref['lengths']), kw
         assert np.array_equal(ends, ref['ends']), kw
         assert np.array_equal(hist, ref['hist']), kw
+
+
+@pytest.mark.parametrize('mem,use_table', [(2, True), (1, False), (0, True)])
+def test_privatised_histogram_in_the_generic_kernels(gpu, mem, use_table):
+    """scattered=True from the first launch: wave-private histogram copies folded at the
+    end, in the kernels that serve other movement models too."""
+    from ssrs_amd import movmodel
+    from oracle import c_oracle
+    rows, cols = 120, 140
+    upd, pot = _random_field_case(rows, cols, 17)
+    rng = np.random.default_rng(mem)
+    n = 1500
+    starts = np.stack([rng.integers(0, rows, n), rng.integers(0, cols, n)], 1)
+    ref = c_oracle.simulate_tracks(0., starts, (rows, cols), mem, 1., upd, pot, seed=9, want_traj=False)
+    res = movmodel.simulate_tracks(0., starts, (rows, cols), mem, 1., upd, pot, seed=9,
+                                   use_table=use_table, ring=False, scattered=True)
+    lens, ends, hist = _no_traj_result(res)
+    assert np.array_equal(lens, ref['lengths'])
+    assert np.array_equal(hist, ref['hist'])
