@@ -1303,9 +1303,9 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_visits(const uint32_t *__re
     const uint32_t base = brow * cols;
     const uint32_t wcells = static_cast<uint32_t>(wrows) * cols;
     uint32_t stray = 0;
-    // eight loads in flight per thread: the loop is bound by the latency of the visit
+    // sixteen loads in flight per thread: the loop is bound by the latency of the visit
     // buffer (just written by the stepper), not by the LDS atomics
-    constexpr int kU = 8;
+    constexpr int kU = 16;
 #pragma unroll
     for (int x = 0; x < kXcd; ++x)
         for (uint32_t j = threadIdx.x; j < nslots[x]; j += kBinThreads * kU) {
