@@ -204,9 +204,11 @@ size_t ssrs_tracks_workspace_bytes_ex(int64_t ntracks, int rows, int cols, int h
  * compute_presence_counts (movmodel.py:410-419).
  *   updraft    f64 (rows, cols) or NULL;  potential f32 (rows, cols) or NULL
  *              (both NULL = 'drw' mode, simulator.py:370-381)
- *   table      from ssrs_transition_table_build, or NULL to gather the 3x3
- *              windows of updraft/potential directly; when given, updraft and
- *              potential are not read
+ *   table      from ssrs_transition_table_build (f64 rows; updraft and potential are
+ *              then not read), from ssrs_transition_ring_build with the flag
+ *              SSRS_TRACKS_RING_TABLE (updraft / potential are read for the exact
+ *              decision of near-ties), or NULL to gather the 3x3 windows of
+ *              updraft/potential directly
  *   start_rc   int32 (ntracks, 2) [row, col]
  *   seed       sim_seed + real_id (simulator.py:352); track_id_base = global id
  *              of track 0 of this call (multi-GPU shards pass their offset)
