@@ -485,3 +485,19 @@ def test_privatised_histogram_in_the_generic_kernels(gpu, mem, use_table):
     lens, ends, hist = _no_traj_result(res)
     assert np.array_equal(lens, ref['lengths'])
     assert np.array_equal(hist, ref['hist'])
+
+
+def test_no_histogram_requested(gpu):
+    """want_hist=False: no visit buffer, no atomics; lengths and end cells only."""
+    from ssrs_amd import movmodel
+    from oracle import c_oracle
+    rows, cols = 90, 110
+    upd, pot = _random_field_case(rows, cols, 23)
+    rng = np.random.default_rng(1)
+    starts = np.stack([rng.integers(0, rows, 400), rng.integers(0, cols, 400)], 1)
+    ref = c_oracle.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=2, want_traj=False)
+    for kw in (dict(use_table=True, ring=True), dict(use_table=True, ring=False), dict(use_table=False)):
+        res = movmodel.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=2, want_hist=False, **kw)
+        assert res.hist is None
+        assert np.array_equal(res.lengths.cpu().numpy(), ref['lengths']), kw
+        assert np.array_equal(res.ends.cpu().numpy(), ref['ends']), kw
