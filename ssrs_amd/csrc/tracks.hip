@@ -676,9 +676,9 @@ __global__ __launch_bounds__(kBlock) void k_tracks_init(
     state[t] = s;
 }
 
-// LEAN = the production case (memory_parameter == 1, no trajectory output): the
-// trajectory stores, the history loop and the running mask are compiled out.
-template <int MODE, bool LEAN = false>
+// The general stepper: any movement model, any data path, optional trajectory output.
+// The reference's default configuration runs in k_step_lean instead.
+template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
 {
     TrackCtl *ctl = a.ctl;
@@ -706,10 +706,10 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
                             static_cast<long long>(a.launch) * a.steps;
     const int release = rel64 > 0x7fffffffLL ? 0x7fffffff : (rel64 < 0 ? 0 : static_cast<int>(rel64));
     const unsigned long long track = a.track_base + static_cast<unsigned long long>(t);
-    const long long toff = (!LEAN && a.traj && active) ? a.traj_off[t] : 0;
+    const long long toff = (a.traj && active) ? a.traj_off[t] : 0;
     // room of this track in traj: a caller whose offsets do not come from this
     // very simulation must not be able to make the kernel write out of bounds
-    const long long troom = (!LEAN && a.traj && active) ? a.traj_off[t + 1] - toff : 0;
+    const long long troom = (a.traj && active) ? a.traj_off[t + 1] - toff : 0;
     uint32_t pend_a = 0, pend_b = 0;   // words (2,3) of the current Philox block
     bool have_pending = false;
     uint32_t moved = 0;
@@ -737,19 +737,8 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
         }
     };
     double2 t0 = {0.0, 0.0}, t1 = t0, t2 = t0, t3 = t0;      // prefetched table entry
-    // LEAN: only the three admissible cells of the next step are fetched (the
-    // previous move is known when the fetch is issued), 24 B instead of 64 B
-    double ta = 0.0, tb = 0.0, tc = 0.0;
-    uint32_t cand = 0;
-    (void)ta; (void)tb; (void)tc; (void)cand;
     auto fetch_entry = [&]() {
-        if (MODE == MODE_TABLE && LEAN) {
-            cand = candidates_of(dirs & 0xFu);
-            const double *src = a.table + (static_cast<size_t>(er) * a.cols + ec) * 8;
-            ta = src[cand & 7u];
-            tb = src[(cand >> 3) & 7u];
-            tc = src[cand >> 6];
-        } else if (MODE == MODE_TABLE) {
+        if (MODE == MODE_TABLE) {
             const double2 *src = reinterpret_cast<const double2 *>(
                 a.table + (static_cast<size_t>(er) * a.cols + ec) * 8);
             t0 = src[0]; t1 = src[1]; t2 = src[2]; t3 = src[3];
@@ -782,7 +771,7 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
                 const double u = words_to_uniform(wa, wb);
                 // ---- direction memory (movmodel.py:307-309)
                 uint32_t mask = kAllButCentre;
-                if (LEAN || a.memory == 1) {         // the reference default: last move only
+                if (a.memory == 1) {                 // the reference default: last move only
                     mask = restriction_of(dirs & 0xFu);
                 } else if (a.memory == 0) {
                     mask = run;
@@ -795,26 +784,7 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
                 }
                 // ---- weights + decision
                 int idx = -1;
-                if (MODE == MODE_TABLE && LEAN) {
-                    // first step of a track (no previous move: 8 admissible cells) and
-                    // near-ties go to the exact sequence on the full row
-                    if (a.fast && (dirs & 0xFu) != 4u) {
-                        const int sel = choose_three_fast(ta, tb, tc, u);
-                        const uint32_t slot = (cand >> (3 * (sel < 0 ? 0 : sel))) & 7u;
-                        idx = sel < 0 ? -1 : static_cast<int>(slot + (slot >= 4u ? 1u : 0u));
-                    }
-                    if (__builtin_expect(idx < 0, 0)) {
-                        const double *src = a.table + (static_cast<size_t>(er) * a.cols + ec) * 8;
-                        double o[8];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) o[j] = __builtin_nontemporal_load(src + j);
-                        const double w[9] = {o[0], o[1], o[2], o[3], 0.0, o[4], o[5], o[6], o[7]};
-                        double pr[9];
-#pragma unroll
-                        for (int j = 0; j < 9; ++j) pr[j] = a.prior[j];
-                        idx = choose_move(w, pr, a.nu, mask, u, false);
-                    }
-                } else if (MODE == MODE_TABLE) {
+                if (MODE == MODE_TABLE) {
                     const double tt[8] = {t0.x, t0.y, t1.x, t1.y, t2.x, t2.y, t3.x, t3.y};
                     if (a.fast) idx = choose_table_fast(tt, mask, u);
                     if (__builtin_expect(idx < 0, 0)) {
@@ -849,12 +819,12 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
                 row = er + idx / 3 - 1;
                 col = ec + idx % 3 - 1;
                 dirs = (dirs << 4) | static_cast<uint32_t>(idx);
-                if (!LEAN && a.memory == 0) run &= restriction_of(static_cast<uint32_t>(idx));
+                if (a.memory == 0) run &= restriction_of(static_cast<uint32_t>(idx));
                 ++k;
                 ++moved;
                 stepped = true;
                 loop_head();                       // head of the NEXT step
-                if (!LEAN && a.traj && k < troom)
+                if (a.traj && k < troom)
                     reinterpret_cast<uint32_t *>(a.traj)[toff + k] =
                         static_cast<uint32_t>(row & 0xFFFF) | (static_cast<uint32_t>(col) << 16);
             }
@@ -1373,7 +1343,7 @@ struct Workspace {
     unsigned long long *keys[2];
     void *sort_temp;
     size_t sort_temp_bytes;
-    uint32_t *visits[2];         // double-buffered: binning of launch L overlaps stepping of L+1
+    uint32_t *visits;            // [kVisitSteps][visit_stride] visited cells of one launch
     long long visit_stride;
     uint32_t cap;                // slots per XCD list
 };
@@ -1417,7 +1387,7 @@ static size_t workspace_layout(int64_t n, char *base, Workspace *ws)
     const long long stride = static_cast<long long>(slots);
     // one buffer: binning runs on the launch stream right after its stepper launch
     // (a second buffer would only be needed to overlap it with the next launch)
-    if (ws) { ws->visits[0] = ws->visits[1] = reinterpret_cast<uint32_t *>(base + off); ws->visit_stride = stride; }
+    if (ws) { ws->visits = reinterpret_cast<uint32_t *>(base + off); ws->visit_stride = stride; }
     off = align_up(off + sizeof(uint32_t) * static_cast<size_t>(stride) * kVisitSteps, 256);
     return off;
 }
@@ -1429,14 +1399,6 @@ static uint32_t *pinned_counts()
     if (!buf && hipHostMalloc(reinterpret_cast<void **>(&buf), 256 * sizeof(uint32_t)) != hipSuccess)
         buf = nullptr;
     return buf;
-}
-
-// side stream for the histogram binning kernels, one per host thread
-static hipStream_t side_stream()
-{
-    static thread_local hipStream_t s = nullptr;
-    if (!s && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;
-    return s;
 }
 
 }  // namespace ssrs
@@ -1621,15 +1583,12 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
         SSRS_REQUIRE(table && updraft && lean && a.fast && (S & 1) == 0,
                      "ssrs_tracks_simulate: SSRS_TRACKS_RING_TABLE needs table + updraft, memory_parameter 1, "
                      "scaling_parameter 1, no trajectory output, no EXACT_ONLY and an even steps_per_launch");
-    // binning needs the coherent front (a step's visits fall into a few rows)
-    // The binning kernel runs on the SAME stream, after its stepper launch.  Running it
-    // on a side stream to overlap the next launch was measured and rejected: its
-    // 1024-thread / 120-KB-LDS blocks crowd the latency-bound stepper waves (stepper
-    // 6.4 -> 10.2 ms, binning 1.4 -> 3.5 ms; profiles/r01_notes.md).
-    constexpr bool kOverlapBinning = false;   // needs two visit buffers (workspace_layout) if enabled
-    hipStream_t st2 = kOverlapBinning ? side_stream() : st;
+    // binning needs the coherent front (a step's visits fall into a few rows).  The
+    // binning kernel runs on the SAME stream, after its stepper launch: running it on a
+    // side stream to overlap the next launch was measured and rejected (its 1024-thread /
+    // 120-KB-LDS blocks crowd the latency-bound stepper waves: stepper 6.4 -> 10.2 ms,
+    // binning 1.4 -> 3.5 ms; profiles/r01_notes.md).
     const bool binning = hist != nullptr && coherent && S <= kVisitSteps &&
-                         (!kOverlapBinning || st2 != nullptr) &&
                          (p->flags & SSRS_TRACKS_NO_BINNING) == 0 && p->cols <= kBinCells;
     a.visits = nullptr;
     a.visit_stride = ws.visit_stride;
@@ -1651,14 +1610,6 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
     a.ncopies = 1;
     a.zmask = ring ? reinterpret_cast<const uint8_t *>(table) + ring_mask_offset(p->rows, p->cols) : nullptr;
     unsigned long long seen_steps = 0, seen_strays = 0;
-    hipEvent_t ev_step[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
-    bool done_valid[2] = {false, false};
-    if (binning)
-        for (int i = 0; i < 2; ++i) {
-            SSRS_HIP_CHECK(hipEventCreateWithFlags(&ev_step[i], hipEventDisableTiming));
-            SSRS_HIP_CHECK(hipEventCreateWithFlags(&ev_done[i], hipEventDisableTiming));
-        }
-
     // Launch loop.  Launches are queued kBatch deep; the live count of a batch
     // is copied back asynchronously and examined while the next batch runs, so
     // the GPU never waits on the host.  Launches past the end see count 0.
@@ -1680,7 +1631,6 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
             a.list_in = (launch == 0 && !coherent) ? nullptr : ws.list[launch & 1];
             a.list_out = ws.list[(launch + 1) & 1];
             const unsigned blocks = kXcd * ((upper + kBlock - 1) / kBlock);
-            const int vb = launch & 1;
             a.visits = nullptr;
             if (!binning_on && scattered && copies_ptr && !copies_live) {
                 // first scattered launch: zero the private copies, count into them from now on
@@ -1692,10 +1642,7 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
                 a.hist_copies = copies_ptr;
                 a.ncopies = ncopies;
             }
-            if (binning_on) {
-                a.visits = ws.visits[vb];
-                if (kOverlapBinning && done_valid[vb]) (void)hipStreamWaitEvent(st, ev_done[vb], 0);   // buffer free again
-            }
+            if (binning_on) a.visits = ws.visits;
             if (profile) {
                 hipEvent_t e;
                 if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); ev_prof.push_back(e); }
@@ -1705,8 +1652,7 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
                 if (ring && scattered && !binning_on) hipLaunchKernelGGL((k_step_lean<true, true>), dim3(blocks), dim3(kBlock), 0, st, a);
                 else if (ring) hipLaunchKernelGGL((k_step_lean<true, false>), dim3(blocks), dim3(kBlock), 0, st, a);
                 else if (lean && a.fast && (S & 1) == 0) hipLaunchKernelGGL((k_step_lean<false, false>), dim3(blocks), dim3(kBlock), 0, st, a);
-                else if (lean) hipLaunchKernelGGL((k_step_tracks<MODE_TABLE, true>), dim3(blocks), dim3(kBlock), 0, st, a);
-                else hipLaunchKernelGGL((k_step_tracks<MODE_TABLE, false>), dim3(blocks), dim3(kBlock), 0, st, a);
+                else hipLaunchKernelGGL(k_step_tracks<MODE_TABLE>, dim3(blocks), dim3(kBlock), 0, st, a);
                 break;
             case MODE_FLUIDFLOW: hipLaunchKernelGGL(k_step_tracks<MODE_FLUIDFLOW>, dim3(blocks), dim3(kBlock), 0, st, a); break;
             case MODE_UPDRAFT: hipLaunchKernelGGL(k_step_tracks<MODE_UPDRAFT>, dim3(blocks), dim3(kBlock), 0, st, a); break;
@@ -1717,24 +1663,14 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
                 if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); ev_bin.push_back(e); }
             }
             if (binning_on) {
-                // binning of this launch runs on the side stream, overlapping the next
-                // stepper launch (which writes the other visit buffer)
-                if (kOverlapBinning) {
-                    (void)hipEventRecord(ev_step[vb], st);
-                    (void)hipStreamWaitEvent(st2, ev_step[vb], 0);
-                }
                 hipEvent_t b0 = nullptr, b1 = nullptr;
-                if (profile && hipEventCreate(&b0) == hipSuccess) (void)hipEventRecord(b0, st2);
-                hipLaunchKernelGGL(k_bin_visits, dim3(S), dim3(kBinThreads), 0, st2, ws.visits[vb], ws.visit_stride,
+                if (profile && hipEventCreate(&b0) == hipSuccess) (void)hipEventRecord(b0, st);
+                hipLaunchKernelGGL(k_bin_visits, dim3(S), dim3(kBinThreads), 0, st, ws.visits, ws.visit_stride,
                                    ws.ctl, launch & 3, hist, p->rows, p->cols, ws.cap);
                 if (profile && b0 && hipEventCreate(&b1) == hipSuccess) {
-                    (void)hipEventRecord(b1, st2);
+                    (void)hipEventRecord(b1, st);
                     ev_hist.push_back(b0);
                     ev_hist.push_back(b1);
-                }
-                if (kOverlapBinning) {
-                    (void)hipEventRecord(ev_done[vb], st2);
-                    done_valid[vb] = true;
                 }
             }
             if (hipGetLastError() != hipSuccess) { rc = set_error(SSRS_ERR_HIP, "stepper launch failed"); break; }
@@ -1782,9 +1718,6 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
             seen_strays = tot[1];
         }
     }
-    if (binning)
-        for (int i = 0; i < 2; ++i)
-            if (done_valid[i]) (void)hipStreamWaitEvent(st, ev_done[i], 0);    // histogram complete on `stream`
     if (copies_live && rc == SSRS_OK)
         hipLaunchKernelGGL(k_fold_copies, dim3(4096), dim3(kBlock), 0, st, copies_ptr, ncopies, ncell, hist);
     if (profile) {
@@ -1823,10 +1756,6 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
     for (hipEvent_t e : ev_prof) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_bin) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_hist) (void)hipEventDestroy(e);
-    for (int i = 0; i < 2; ++i) {
-        if (ev_step[i]) (void)hipEventDestroy(ev_step[i]);
-        if (ev_done[i]) (void)hipEventDestroy(ev_done[i]);
-    }
     for (int i = 0; i < kRing; ++i) (void)hipEventDestroy(ev_batch[i]);
     (void)hipEventDestroy(ev_first);
     (void)hipEventDestroy(ev_last);
