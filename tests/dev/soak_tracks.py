@@ -1,0 +1,48 @@
+"""Randomised soak: random shapes, fields, headings, batch sizes and switches; every GPU
+data path against the C oracle.  python tests/dev/soak_tracks.py [seconds]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+from ssrs_amd import movmodel
+from oracle import c_oracle
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.
+t0 = time.time(); n_case = 0; n_steps = 0
+master = np.random.default_rng(2026)
+while time.time() - t0 < budget:
+    seed = int(master.integers(0, 2**31))
+    rng = np.random.default_rng(seed)
+    rows, cols = int(rng.integers(5, 400)), int(rng.integers(5, 500))
+    n = int(rng.choice([1, 7, 64, 65, 300, 2000, 9000, 20000]))
+    dirn = float(rng.choice([0., 45., 90., 135., 180., 225., 270., 315., rng.uniform(0, 360)]))
+    kind = rng.choice(['rough', 'smooth', 'flat', 'speckle', 'nan'])
+    upd = np.abs(rng.normal(0.8, 0.6, (rows, cols)))
+    if kind in ('speckle', 'nan'):
+        upd[rng.random((rows, cols)) < 0.5] = 0.0
+    ramp = 1000. * (1 - np.arange(rows)[:, None] / max(rows - 1., 1.))
+    if kind == 'flat':
+        pot = np.full((rows, cols), 7.0, dtype=np.float32)
+    elif kind == 'smooth':
+        pot = (ramp + 0 * upd).astype(np.float32)
+    else:
+        pot = (ramp + rng.normal(0, rng.choice([0.01, 1.0, 30.0]), (rows, cols))).astype(np.float32)
+    if kind == 'nan':
+        upd[rng.random((rows, cols)) < 0.01] = np.nan
+    starts = np.stack([rng.integers(0, rows, n), rng.integers(0, cols, n)], 1)
+    s = int(rng.integers(0, 2**31))
+    ref = c_oracle.simulate_tracks(dirn, starts, (rows, cols), 1, 1., upd, pot, seed=s, want_traj=False)
+    spl = int(rng.choice([0, 2, 16, 64, 512]))
+    for kw in (dict(use_table=True, ring=True), dict(use_table=True, ring=True, scattered=True),
+               dict(use_table=True, ring=False), dict(use_table=True, ring=False, scattered=True), dict(use_table=False),
+               dict(use_table=True, ring=True, schedule=False), dict(use_table=True, ring=True, binning=False)):
+        res = movmodel.simulate_tracks(dirn, starts, (rows, cols), 1, 1., upd, pot, seed=s, steps_per_launch=spl, **kw)
+        ok = (np.array_equal(res.lengths.cpu().numpy(), ref['lengths']) and
+              np.array_equal(res.ends.cpu().numpy(), ref['ends']) and
+              np.array_equal(res.hist.cpu().numpy().view(np.uint32), ref['hist']))
+        if not ok:
+            print('MISMATCH', dict(seed=seed, rows=rows, cols=cols, n=n, dirn=dirn, kind=kind, spl=spl), kw, flush=True)
+            sys.exit(1)
+    n_case += 1; n_steps += int(ref['steps'])
+    if n_case % 20 == 0:
+        print(f'{n_case} cases, {n_steps:.3e} oracle steps, {time.time() - t0:.0f} s', flush=True)
+print(f'soak ok: {n_case} cases x 7 GPU variants, {n_steps:.3e} steps each', flush=True)
