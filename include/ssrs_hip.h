@@ -95,6 +95,22 @@ int ssrs_updraft_from_dem(const void *dem, int dem_type, double res, double wspe
                           double threshold, double *usable, int rows, int cols,
                           void *stream);
 
+/* Snapshot / seasonal form of ssrs_updraft_from_dem (simulator.py:200-215 with the wind
+ * preparation of :765-792 folded in): `batch` wind snapshots given as speed / direction
+ * samples on a regular nx x ny lattice (as ssrs_wind_from_lattice; x0, y0, dx, dy in km,
+ * the raster's cell size is res / 1000 km) -> orograph (batch, rows, cols) f32 and / or
+ * usable updraft (batch, rows, cols) f64.  The DEM is read once for the whole batch and
+ * no per-cell wind raster is materialised: bilinear east / north components at the cell,
+ * w = -(Y north + X east) / sqrt(d^2 + X^2 + Y^2) (the wind speed cancels).
+ * workspace: ssrs_lattice_workspace_bytes(nx, ny, batch) bytes of device scratch. */
+size_t ssrs_lattice_workspace_bytes(int nx, int ny, int batch);
+int ssrs_updraft_from_dem_lattice(const void *dem, int dem_type, double res,
+                                  const double *lattice_speed, const double *lattice_dirn,
+                                  int nx, int ny, double x0, double y0, double dx, double dy,
+                                  double min_updraft_val, float *orograph, double threshold,
+                                  double *usable, int rows, int cols, int batch,
+                                  void *workspace, size_t workspace_bytes, void *stream);
+
 /* Wind preparation of snapshot / seasonal modes (ssrs/simulator.py:778-792):
  * `batch` sets of speed/direction samples on a regular nx x ny lattice (origin
  * x0,y0 and spacings dx,dy in the raster's length unit, cell_size likewise;

@@ -537,6 +537,158 @@ __global__ __launch_bounds__(kBlock) void k_wind_lattice(
 
 }  // namespace ssrs
 
+namespace ssrs {
+
+// Lattice speed / direction -> east and north components (simulator.py:784-785), once
+// per lattice point instead of once per raster cell and corner.
+__global__ __launch_bounds__(kBlock) void k_lattice_components(const double *__restrict__ lat_speed,
+                                                              const double *__restrict__ lat_dirn,
+                                                              size_t n, double *__restrict__ east,
+                                                              double *__restrict__ north)
+{
+    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * kBlock) {
+        const double s = lat_speed[i], a = lat_dirn[i] * kPi / 180.0;
+        east[i] = s * sin(a);
+        north[i] = s * cos(a);
+    }
+}
+
+// Snapshot / seasonal K1: DEM tile in LDS -> Horn sums once per cell, then for every
+// snapshot b the wind at the cell (bilinear in the lattice's east / north components,
+// as k_wind_lattice) and the updraft in the trig-free form of k_updraft_from_dem: with
+// (cos w, sin w) = (north, east) / speed the wind speed cancels,
+//     w = -(Y north + X east) / sqrt(d^2 + X^2 + Y^2),
+// so neither the per-cell wind rasters (16 B per cell and snapshot written and read
+// again) nor atan2 / sin / cos per cell are needed: 8 B read per cell for the whole
+// batch, 4-12 B written per cell and snapshot.
+struct LatticeArgs {
+    const double *east, *north;       // (batch, ny, nx)
+    int nx, ny, batch;
+    double x0, y0, inv_dx, inv_dy, cell;
+};
+
+template <typename Tin>
+__global__ __launch_bounds__(kBlock) void k_updraft_from_dem_lattice(
+    const Tin *__restrict__ dem, FusedArgs fa, LatticeArgs la, float *__restrict__ orograph,
+    double *__restrict__ usable, int rows, int cols, int tiles_x, int ntiles)
+{
+    __shared__ double tile[LW * LH];
+    const int t = xcd_tile(blockIdx.x, ntiles);
+    const int r0 = (t / tiles_x) * TH, c0 = (t % tiles_x) * TW;
+    stage_dem_tile(dem, rows, cols, r0, c0, tile);
+    const int lc = threadIdx.x % TW + 1;
+    const int c = c0 + lc - 1;
+    if (c >= cols) return;
+    constexpr int kRowsPerWave = TH / (kBlock / TW);
+    const int lr0 = (threadIdx.x / TW) * kRowsPerWave + 1;
+    // lattice column of this thread's cells (the same for all its rows)
+    double fx = (c * la.cell - la.x0) * la.inv_dx;
+    fx = fx < 0.0 ? 0.0 : (fx > la.nx - 1.0 ? la.nx - 1.0 : fx);
+    int ix = static_cast<int>(fx);
+    ix = ix > la.nx - 2 ? (la.nx > 1 ? la.nx - 2 : 0) : ix;
+    const double tx = la.nx > 1 ? fx - ix : 0.0;
+    const int jx1 = la.nx > 1 ? 1 : 0;
+    const size_t ncell = static_cast<size_t>(rows) * cols;
+    for (int lr = lr0; lr < lr0 + kRowsPerWave; ++lr) {
+        const int r = r0 + lr - 1;
+        if (r >= rows) break;
+        const double *m = tile + (lr - 1) * LW + lc, *z = tile + lr * LW + lc, *p = tile + (lr + 1) * LW + lc;
+        const bool interior = r > 0 && c > 0 && r < rows - 1 && c < cols - 1;
+        // un-normalised Horn sums (layers.py:78-90; "x" = row axis)
+        const double X = (p[1] + 2 * p[0] + p[-1]) - (m[1] + 2 * m[0] + m[-1]);
+        const double Y = (m[1] + 2 * z[1] + p[1]) - (m[-1] + 2 * z[-1] + p[-1]);
+        const double rs = rsqrt(fa.d2 + (X * X + Y * Y));
+        double fy = (r * la.cell - la.y0) * la.inv_dy;
+        fy = fy < 0.0 ? 0.0 : (fy > la.ny - 1.0 ? la.ny - 1.0 : fy);
+        int iy = static_cast<int>(fy);
+        iy = iy > la.ny - 2 ? (la.ny > 1 ? la.ny - 2 : 0) : iy;
+        const double ty = la.ny > 1 ? fy - iy : 0.0;
+        const size_t o00 = static_cast<size_t>(iy) * la.nx + ix;
+        const size_t o10 = o00 + (la.ny > 1 ? la.nx : 0);
+        const double w00 = (1.0 - tx) * (1.0 - ty), w01 = tx * (1.0 - ty), w10 = (1.0 - tx) * ty, w11 = tx * ty;
+        const size_t i = static_cast<size_t>(r) * cols + c;
+        for (int b = 0; b < la.batch; ++b) {
+            const double *le = la.east + static_cast<size_t>(b) * la.nx * la.ny;
+            const double *ln = la.north + static_cast<size_t>(b) * la.nx * la.ny;
+            // same accumulation order as k_wind_lattice
+            double east = 0.0, north = 0.0;
+            east += w00 * le[o00]; north += w00 * ln[o00];
+            east += w01 * le[o00 + jx1]; north += w01 * ln[o00 + jx1];
+            east += w10 * le[o10]; north += w10 * ln[o10];
+            east += w11 * le[o10 + jx1]; north += w11 * ln[o10 + jx1];
+            double w = 0.0;
+            if (interior) {
+                if (X != 0.0) {
+                    const double P = -(Y * north + X * east);
+                    if (P > 0.0) w = P * rs;
+                } else {
+                    // dz_dx == 0: the reference substitutes 1e-10 for the aspect only (layers.py:124)
+                    const double spd = sqrt(east * east + north * north);
+                    const double dzdy = Y / fa.d, dx = 1e-10;
+                    const double g2 = dzdy * dzdy, gp2 = dx * dx + g2;
+                    const double proj = spd > 0.0 ? -(dzdy * north + dx * east) : 0.0;
+                    if (proj > 0.0 && g2 > 0.0) w = proj * sqrt(g2 / (gp2 * (1.0 + g2)));
+                }
+            }
+            w = w > fa.min_val ? w : fa.min_val;
+            const float w32 = static_cast<float>(w);
+            if (orograph) orograph[b * ncell + i] = w32;
+            if (usable)
+                usable[b * ncell + i] = usable_updraft_fast(static_cast<double>(w32), fa.thr, fa.inv_thr, fa.scale);
+        }
+    }
+}
+
+}  // namespace ssrs
+
+extern "C" size_t ssrs_lattice_workspace_bytes(int nx, int ny, int batch)
+{
+    if (nx <= 0 || ny <= 0 || batch <= 0) return 0;
+    return static_cast<size_t>(nx) * ny * batch * 2 * sizeof(double);
+}
+
+extern "C" int ssrs_updraft_from_dem_lattice(const void *dem, int dem_type, double res,
+                                             const double *lattice_speed, const double *lattice_dirn,
+                                             int nx, int ny, double x0, double y0, double dx, double dy,
+                                             double min_val, float *orograph, double threshold,
+                                             double *usable, int rows, int cols, int batch,
+                                             void *workspace, size_t workspace_bytes, void *stream)
+{
+    SSRS_REQUIRE(dem && lattice_speed && lattice_dirn, "ssrs_updraft_from_dem_lattice: NULL pointer");
+    SSRS_REQUIRE(rows >= 3 && cols >= 3 && nx >= 1 && ny >= 1 && batch >= 1,
+                 "ssrs_updraft_from_dem_lattice: bad sizes");
+    SSRS_REQUIRE(res > 0.0 && dx > 0.0 && dy > 0.0, "ssrs_updraft_from_dem_lattice: res, dx, dy must be > 0");
+    SSRS_REQUIRE(dem_type == SSRS_F32 || dem_type == SSRS_F64, "ssrs_updraft_from_dem_lattice: bad element type");
+    SSRS_REQUIRE(!(usable && !(threshold > 0.0)),
+                 "ssrs_updraft_from_dem_lattice: usable requested without a positive threshold");
+    SSRS_REQUIRE(workspace && workspace_bytes >= ssrs_lattice_workspace_bytes(nx, ny, batch),
+                 "ssrs_updraft_from_dem_lattice: workspace too small");
+    if (!orograph && !usable) return SSRS_OK;
+    hipStream_t st = as_stream(stream);
+    const size_t npts = static_cast<size_t>(nx) * ny * batch;
+    double *east = static_cast<double *>(workspace), *north = east + npts;
+    hipLaunchKernelGGL(k_lattice_components, dim3(stream_grid(npts)), dim3(kBlock), 0, st, lattice_speed,
+                       lattice_dirn, npts, east, north);
+    const int tx = (cols + TW - 1) / TW, ty = (rows + TH - 1) / TH, nt = tx * ty;
+    FusedArgs fa = {};
+    fa.d = 8 * res;
+    fa.d2 = fa.d * fa.d;
+    fa.min_val = min_val;
+    fa.thr = threshold;
+    fa.inv_thr = threshold > 0.0 ? 1.0 / threshold : 0.0;
+    fa.scale = threshold > 0.0 ? threshold / (exp(1.0) - 1.0) : 0.0;
+    LatticeArgs la = {east, north, nx, ny, batch, x0, y0, 1.0 / dx, 1.0 / dy, res / 1000.0};
+    if (dem_type == SSRS_F64)
+        hipLaunchKernelGGL((k_updraft_from_dem_lattice<double>), dim3(nt), dim3(kBlock), 0, st,
+                           static_cast<const double *>(dem), fa, la, orograph, usable, rows, cols, tx, nt);
+    else
+        hipLaunchKernelGGL((k_updraft_from_dem_lattice<float>), dim3(nt), dim3(kBlock), 0, st,
+                           static_cast<const float *>(dem), fa, la, orograph, usable, rows, cols, tx, nt);
+    SSRS_HIP_CHECK(hipGetLastError());
+    return SSRS_OK;
+}
+
 extern "C" int ssrs_wind_from_lattice(const double *lattice_speed, const double *lattice_dirn,
                                       int nx, int ny, double x0, double y0, double dx, double dy,
                                       double cell_size, double *wspeed, double *wdirn, int rows,

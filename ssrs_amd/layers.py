@@ -143,3 +143,44 @@ def updraft_from_dem(z_mat, res, wspeed, wdirn, threshold=None, min_updraft_val=
         rows, cols, stream_ptr()))
     return (None if oro is None else like_input(oro, z_mat),
             None if use is None else like_input(use, z_mat))
+
+
+def updraft_from_dem_lattice(z_mat, res, x_km, y_km, wspeed, wdirn, threshold=None,
+                             min_updraft_val=0., want_orograph=True):
+    """Snapshot / seasonal raster in one pass: DEM + wind samples on a regular lattice
+    (x_km[nx], y_km[ny] relative to the south-west cell centre; wspeed / wdirn (ny, nx)
+    or (B, ny, nx)) -> (orograph f32 | None, usable f64 | None), shaped (rows, cols) for
+    one snapshot, else (B, rows, cols).  Equivalent to wind.interpolate_wind_lattice +
+    slope_aspect + orographic_updraft without materialising any of their rasters."""
+    import numpy as np
+    dem = float_dev(z_mat)
+    rows, cols = _shape2(dem)
+    x = np.asarray(x_km, dtype=np.float64)
+    y = np.asarray(y_km, dtype=np.float64)
+    nx, ny = x.size, y.size
+    dx = float(x[1] - x[0]) if nx > 1 else 1.0
+    dy = float(y[1] - y[0]) if ny > 1 else 1.0
+    if nx > 2 and not np.allclose(np.diff(x), dx) or ny > 2 and not np.allclose(np.diff(y), dy):
+        raise ValueError('wind lattice must be uniformly spaced')
+    ws = to_dev(wspeed, torch.float64)
+    wd = to_dev(wdirn, torch.float64)
+    single = ws.dim() == 2
+    if single:
+        ws, wd = ws[None], wd[None]
+    if tuple(ws.shape[1:]) != (ny, nx) or ws.shape != wd.shape:
+        raise ValueError(f'lattice arrays must be (ny, nx) = {(ny, nx)}')
+    batch = int(ws.shape[0])
+    oro = torch.empty((batch, rows, cols), dtype=torch.float32, device=dem.device) if want_orograph else None
+    use = torch.empty((batch, rows, cols), dtype=torch.float64, device=dem.device) \
+        if threshold is not None else None
+    nbytes = nat.lib().ssrs_lattice_workspace_bytes(nx, ny, batch)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dem.device)
+    nat.check(nat.lib().ssrs_updraft_from_dem_lattice(
+        nat.ptr(dem), ftype(dem), C.c_double(res), nat.ptr(ws.contiguous()), nat.ptr(wd.contiguous()),
+        nx, ny, C.c_double(x[0]), C.c_double(y[0]), C.c_double(dx), C.c_double(dy),
+        C.c_double(min_updraft_val), nat.ptr(oro), C.c_double(-1. if threshold is None else threshold),
+        nat.ptr(use), rows, cols, batch, nat.ptr(scratch), C.c_size_t(nbytes), stream_ptr()))
+    if single:
+        oro = None if oro is None else oro[0]
+        use = None if use is None else use[0]
+    return oro, use

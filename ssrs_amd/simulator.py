@@ -218,9 +218,28 @@ class Simulator(Config):
         terrain is read once for all cases."""
         print('Computing orographic updrafts..', end="")
         start_time = time.time()
+        batch = 8
+        # DEM-only terrain and wind on one regular lattice: the fused kernel (DEM read once
+        # per batch, no per-cell wind rasters, no slope / aspect rasters)
+        lattice = all('x_km' in it for it in self._wind) and \
+            not ('Slope' in self._terrain or 'Aspect' in self._terrain) and \
+            all(np.array_equal(it['x_km'], self._wind[0]['x_km']) and
+                np.array_equal(it['y_km'], self._wind[0]['y_km']) for it in self._wind)
+        if lattice:
+            dem = to_dev(self.get_terrain_elevation(), torch.float64)
+            for b0 in range(0, len(self._wind), batch):
+                chunk = self._wind[b0:b0 + batch]
+                oro, _ = layers.updraft_from_dem_lattice(
+                    dem, self.resolution, chunk[0]['x_km'], chunk[0]['y_km'],
+                    np.stack([np.asarray(it['wspeed'], dtype=np.float64) for it in chunk]),
+                    np.stack([np.asarray(it['wdirn'], dtype=np.float64) for it in chunk]))
+                for item, o in zip(chunk, oro):
+                    fname = self._get_orograph_fname(item['case_id'], self.mode_data_dir)
+                    np.save(f'{fname}.npy', o.cpu().numpy())
+            print(f'took {_elapsed(start_time)}', flush=True)
+            return
         slope = to_dev(self.get_terrain_slope(), torch.float64)
         aspect = to_dev(self.get_terrain_aspect(), torch.float64)
-        batch = 8
         for b0 in range(0, len(self._wind), batch):
             chunk = self._wind[b0:b0 + batch]
             ws, wd = [], []

@@ -223,3 +223,35 @@ def test_thermals_blur_exact_and_seeding_statistics(gpu):
     th = thermals.compute_thermals(aspect, 2.0, seed=11)
     np.testing.assert_allclose(th, ndimage.gaussian_filter(seeds, sigma=4, mode='constant'),
                                rtol=1e-12, atol=1e-12)
+
+
+def test_fused_dem_lattice_updraft_equals_the_three_kernel_chain(gpu):
+    """Snapshot / seasonal raster in one pass (ssrs_updraft_from_dem_lattice) against
+    wind interpolation -> slope/aspect -> orographic + threshold: the same numbers up to
+    the orograph's f32 rounding (<= 1 ulp; cells whose value is cancellation noise are
+    compared absolutely), for one snapshot and for a batch; ragged shape."""
+    from ssrs_amd import layers
+    from ssrs_amd.wind import interpolate_wind_lattice
+    from ssrs_amd.synthetic import synthetic_dem, wind_lattice
+    rows, cols, res = 300, 517, 100.
+    z = synthetic_dem((rows, cols), res, seed=9)
+    slope, aspect = layers.slope_aspect(z, res)
+    B = 3
+    lat = [wind_lattice((cols * res / 1000., rows * res / 1000.), phase=0.7 * s) for s in range(B)]
+    x, y = lat[0][0], lat[0][1]
+    ws = np.stack([l[2] for l in lat]); wd = np.stack([l[3] for l in lat])
+    s_r, d_r = interpolate_wind_lattice(x, y, ws, wd, (rows, cols), res)
+    oro_ref, use_ref = layers.orographic_updraft(s_r, d_r, slope, aspect, threshold=0.75)
+    oro, use = layers.updraft_from_dem_lattice(z, res, x, y, ws, wd, threshold=0.75)
+    assert tuple(oro.shape) == (B, rows, cols) and oro.dtype == torch.float32 and use.dtype == torch.float64
+    a, b = oro.cpu().numpy(), oro_ref.cpu().numpy()
+    d = ulp_diff_f32(a, b)
+    noise = np.abs(a.astype(np.float64) - b.astype(np.float64)) < 1e-11
+    assert (d[~noise] <= 1).all(), int(d[~noise].max())
+    assert (d == 0).mean() > 0.99
+    np.testing.assert_allclose(use.cpu().numpy(), use_ref.cpu().numpy(), rtol=2e-5, atol=1e-7)
+    same = a == b
+    np.testing.assert_allclose(use.cpu().numpy()[same], use_ref.cpu().numpy()[same], rtol=1e-12, atol=1e-15)
+    o1, u1 = layers.updraft_from_dem_lattice(z, res, x, y, ws[1], wd[1], threshold=0.75)
+    assert tuple(o1.shape) == (rows, cols)
+    assert torch.equal(o1, oro[1]) and torch.equal(u1, use[1])
