@@ -19,6 +19,29 @@ def shard_range(ntracks, rank, world_size):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def shard_cases(case_ids, rank=None, world_size=None, group=None):
+    """Seasonal / snapshot mode shards by CASE: the wind snapshots are the
+    outer independent unit, each rank takes a contiguous share of them (all of its
+    tracks), and only the per-case normalised presence sums are exchanged.  Without a
+    process group every case stays here."""
+    if rank is None or world_size is None:
+        if not (dist.is_available() and dist.is_initialized()):
+            return list(case_ids)
+        rank, world_size = dist.get_rank(group), dist.get_world_size(group)
+    lo, hi = shard_range(len(case_ids), rank, world_size)
+    return list(case_ids)[lo:hi]
+
+
+def reduce_presence_sum(summary, group=None):
+    """Sum of the per-case normalised presence maps (f64) over ranks, on every rank:
+    the one exchange step of seasonal mode (120-240 MB at 5000 x 6000).  The following
+    /max of plot_presence_map (simulator.py:546) is then the same on all ranks."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return summary
+    dist.all_reduce(summary, op=dist.ReduceOp.SUM, group=group)
+    return summary
+
+
 def reduce_histogram(hist, dst=0, group=None, all_ranks=False, async_op=False):
     """In-place sum of the presence histogram over ranks.
 

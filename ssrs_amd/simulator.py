@@ -202,6 +202,8 @@ class Simulator(Config):
         kernel (DEM -> orograph); with slope/aspect layers injected, the
         elementwise kernel on those layers."""
         print('Computing orographic updrafts..')
+        if self.case_ids[0] not in self.my_case_ids():
+            return
         if 'Slope' in self._terrain or 'Aspect' in self._terrain:
             orograph = layers.compute_orographic_updraft(
                 float(self.uniform_windspeed), float(self.uniform_winddirn),
@@ -221,14 +223,16 @@ class Simulator(Config):
         batch = 8
         # DEM-only terrain and wind on one regular lattice: the fused kernel (DEM read once
         # per batch, no per-cell wind rasters, no slope / aspect rasters)
-        lattice = all('x_km' in it for it in self._wind) and \
+        mine = set(self.my_case_ids())
+        wind = [it for it in self._wind if it['case_id'] in mine]
+        lattice = len(wind) > 0 and all('x_km' in it for it in wind) and \
             not ('Slope' in self._terrain or 'Aspect' in self._terrain) and \
-            all(np.array_equal(it['x_km'], self._wind[0]['x_km']) and
-                np.array_equal(it['y_km'], self._wind[0]['y_km']) for it in self._wind)
+            all(np.array_equal(it['x_km'], wind[0]['x_km']) and
+                np.array_equal(it['y_km'], wind[0]['y_km']) for it in wind)
         if lattice:
             dem = to_dev(self.get_terrain_elevation(), torch.float64)
-            for b0 in range(0, len(self._wind), batch):
-                chunk = self._wind[b0:b0 + batch]
+            for b0 in range(0, len(wind), batch):
+                chunk = wind[b0:b0 + batch]
                 oro, _ = layers.updraft_from_dem_lattice(
                     dem, self.resolution, chunk[0]['x_km'], chunk[0]['y_km'],
                     np.stack([np.asarray(it['wspeed'], dtype=np.float64) for it in chunk]),
@@ -240,8 +244,8 @@ class Simulator(Config):
             return
         slope = to_dev(self.get_terrain_slope(), torch.float64)
         aspect = to_dev(self.get_terrain_aspect(), torch.float64)
-        for b0 in range(0, len(self._wind), batch):
-            chunk = self._wind[b0:b0 + batch]
+        for b0 in range(0, len(wind), batch):
+            chunk = wind[b0:b0 + batch]
             ws, wd = [], []
             for item in chunk:
                 s, d = self._wind_rasters(item)
@@ -370,7 +374,7 @@ class Simulator(Config):
         # stepped concurrently, one HIP stream per worker thread (seasonal mode
         # has many small batches that cannot fill the GPU one at a time).
         def prepare():
-            for case_id in self.case_ids:
+            for case_id in self.my_case_ids():
                 updrafts = self.load_updrafts(case_id, apply_threshold=True)
                 for real_id, updraft in enumerate(updrafts):
                     if self.sim_seed > 0:
@@ -404,7 +408,7 @@ class Simulator(Config):
                     pickle.dump(tracks, fobj)
             return (case_id, real_id), batch
 
-        nitems = len(self.case_ids) * (1 + int(self.thermals_realization_count))
+        nitems = max(1, len(self.my_case_ids())) * (1 + int(self.thermals_realization_count))
         workers = max(1, min(nitems, int(self.max_cores), 8))
 
         def collect(results):
@@ -444,7 +448,7 @@ class Simulator(Config):
         dev = torch.device('cuda', torch.cuda.current_device())
         summary = torch.zeros(self.gridsize, dtype=torch.float64, device=dev)
         self.case_presence = {}
-        for case_id in self.case_ids:
+        for case_id in self.my_case_ids():
             nreal = 1 + int(self.thermals_realization_count)
             case_prob = torch.zeros(self.gridsize, dtype=torch.float64, device=dev)
             for real_id in range(nreal):
@@ -453,9 +457,27 @@ class Simulator(Config):
                 presence.normalise_add(prprob, case_prob)       # prprob /= amax; case += prprob
             presence.normalise_add(case_prob, summary)          # case /= amax; summary += case
             self.case_presence[case_id] = case_prob
+        from .distributed import reduce_presence_sum
+        reduce_presence_sum(summary)                            # cases of the other ranks
         out = presence.normalise_to_f32(summary).cpu().numpy()  # summary /= amax -> f32
-        np.save(os.path.join(self.mode_data_dir, 'summary_presence.npy'), out)
+        if self._rank() == 0:
+            np.save(os.path.join(self.mode_data_dir, 'summary_presence.npy'), out)
         return out
+
+    # ---------------------------------------------------------- multi-GPU
+    @staticmethod
+    def _rank():
+        import torch.distributed as dist
+        return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+    def my_case_ids(self):
+        """Cases this rank simulates: with a torch.distributed process group (one process
+        per GPU) the wind cases are sharded contiguously over the ranks: every
+        rank computes, saves and simulates only its own cases, and compute_presence_map
+        sums the per-case maps over the ranks.  (A single uniform-mode case lands on rank 0;
+        sharding ONE case's tracks over GPUs is what bench.py / distributed.shard_range do.)"""
+        from .distributed import shard_cases
+        return shard_cases(self.case_ids)
 
     def plot_presence_map(self, plot_turbs=True, radius: float = 1000., show=False,
                           minval=0.1, plot_all: bool = False) -> None:

@@ -56,6 +56,15 @@ def _worker(rank, world, port, out_dir):
     h2 = torch.from_numpy(res['hist'].view(np.int32).copy())
     reduce_histogram(h2, all_ranks=True)
     np.save(os.path.join(out_dir, f'all_{rank}.npy'), h2.numpy())
+    # seasonal mode: cases are sharded contiguously, the per-case presence sums are added
+    from ssrs_amd.distributed import shard_cases, reduce_presence_sum
+    cases = [f'case{i}' for i in range(7)]
+    mine = shard_cases(cases)
+    got = [None] * world
+    dist.all_gather_object(got, mine)
+    assert sum(got, []) == cases and max(map(len, got)) - min(map(len, got)) <= 1
+    summ = torch.full((4, 5), float(len(mine)), dtype=torch.float64)
+    assert float(reduce_presence_sum(summ)[0, 0]) == len(cases)
     # the pipelined form bench.py uses: two buffers, reduce i in flight while i + 1 is filled
     bufs = [torch.from_numpy(res['hist'].view(np.int32).copy()) for _ in range(2)]
     works = [reduce_histogram(b, all_ranks=True, async_op=True) for b in bufs]
@@ -88,3 +97,8 @@ def test_reduce_is_noop_without_process_group():
     h = torch.arange(12, dtype=torch.int32).reshape(3, 4)
     assert reduce_histogram(h) is h
     assert reduce_histogram(h, async_op=True) is None
+    from ssrs_amd.distributed import shard_cases, reduce_presence_sum
+    assert shard_cases(['a', 'b', 'c']) == ['a', 'b', 'c']
+    assert shard_cases(['a', 'b', 'c'], rank=1, world_size=2) == ['c']
+    t = torch.ones(3, dtype=torch.float64)
+    assert reduce_presence_sum(t) is t
