@@ -627,6 +627,8 @@ struct StepArgs {
     const uint8_t *zmask;        // ring table's zero-mask bytes (scattered variant), or NULL
     uint32_t *hist_copies;       // privatised histogram copies (scattered batches), or NULL
     int ncopies;
+    uint32_t vis_r, vis_c;       // visit key = row * vis_r + col * vis_c: (cols, 1), or (1, rows) when
+                                 // the front is a column (east / west headings: transposed binning)
 };
 
 __global__ __launch_bounds__(kBlock) void k_tracks_init(
@@ -847,7 +849,8 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
         //  * fallback: one atomic per lane (idle lanes add 0 to their own cell)
         if (a.visits) {
             a.visits[static_cast<long long>(it) * a.visit_stride + i] =
-                stepped ? static_cast<uint32_t>(row) * a.cols + col : 0xFFFFFFFFu;
+                stepped ? __umul24(static_cast<uint32_t>(row), a.vis_r) + __umul24(static_cast<uint32_t>(col), a.vis_c)
+                        : 0xFFFFFFFFu;
         } else if (a.hist) {
             uint32_t *h = a.hist;
             if (a.hist_copies)
@@ -1150,7 +1153,9 @@ __global__ __launch_bounds__(kBlock) void k_step_lean(const StepArgs a)
         // ---- presence histogram (see k_step_tracks)
         const uint32_t cell = __umul24(static_cast<uint32_t>(row), ucols) + static_cast<uint32_t>(col);
         if (a.visits) {
-            a.visits[static_cast<long long>(it) * a.visit_stride + i] = st ? cell : 0xFFFFFFFFu;
+            a.visits[static_cast<long long>(it) * a.visit_stride + i] =
+                st ? __umul24(static_cast<uint32_t>(row), a.vis_r) + __umul24(static_cast<uint32_t>(col), a.vis_c)
+                   : 0xFFFFFFFFu;
         } else if (a.hist) {
             uint32_t *h = a.hist;
             // scattered variant: wave-private copy, so that same-address atomics of
@@ -1330,6 +1335,28 @@ __global__ __launch_bounds__(kBlock) void k_fold_copies(const uint32_t *__restri
         uint32_t s = 0;
         for (int c = 0; c < ncopies; ++c) s += copies[static_cast<size_t>(c) * ncell + i];
         if (s) hist[i] += s;
+    }
+}
+
+// hist (rows x cols) += transpose of hist_t (cols x rows): the transposed histogram that
+// east / west batches bin into (there a step's visits fill a few COLUMNS, which are rows
+// of hist_t, so the LDS window of k_bin_visits and its contiguous flush work unchanged)
+__global__ __launch_bounds__(kBlock) void k_transpose_add(const uint32_t *__restrict__ hist_t, int rows,
+                                                         int cols, uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
+    const int tiles_c = (cols + 31) / 32;
+    const int r0 = (blockIdx.x / tiles_c) * 32, c0 = (blockIdx.x % tiles_c) * 32;
+    for (int j = ty; j < 32; j += 8) {                                // read hist_t[c][r], r fastest
+        const int c = c0 + j, r = r0 + tx;
+        tile[j][tx] = (c < cols && r < rows) ? hist_t[static_cast<size_t>(c) * rows + r] : 0u;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {                                // write hist[r][c], c fastest
+        const int r = r0 + j, c = c0 + tx;
+        const uint32_t v = tile[tx][j];
+        if (r < rows && c < cols && v) hist[static_cast<size_t>(r) * cols + c] += v;
     }
 }
 
@@ -1588,8 +1615,12 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
     // side stream to overlap the next launch was measured and rejected (its 1024-thread /
     // 120-KB-LDS blocks crowd the latency-bound stepper waves: stepper 6.4 -> 10.2 ms,
     // binning 1.4 -> 3.5 ms; profiles/r01_notes.md).
-    const bool binning = hist != nullptr && coherent && S <= kVisitSteps &&
-                         (p->flags & SSRS_TRACKS_NO_BINNING) == 0 && p->cols <= kBinCells;
+    // east / west headings: the front is a column, so the batch bins into a TRANSPOSED
+    // histogram (needs one raster of extra workspace, see below)
+    const bool want_transposed = coherent && std::fabs(geom.sin_t) > std::fabs(geom.cos_t);
+    bool binning = hist != nullptr && coherent && S <= kVisitSteps &&
+                   (p->flags & SSRS_TRACKS_NO_BINNING) == 0 &&
+                   (want_transposed ? p->rows : p->cols) <= kBinCells;
     a.visits = nullptr;
     a.visit_stride = ws.visit_stride;
     bool binning_on = binning && ntracks >= 8192;   // small batches: plain atomics are cheaper
@@ -1603,8 +1634,18 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
     const size_t ws_base = align_up(ssrs_tracks_workspace_bytes(ntracks), 256);
     int ncopies = 0;
     if (hist && workspace_bytes > ws_base) ncopies = static_cast<int>((workspace_bytes - ws_base) / (ncell * sizeof(uint32_t)));
+    uint32_t *extra = reinterpret_cast<uint32_t *>(static_cast<char *>(workspace) + ws_base);
+    // the first extra raster is the transposed histogram of an east / west batch
+    uint32_t *hist_t = nullptr;
+    if (want_transposed && binning_on) {
+        if (ncopies >= 1) { hist_t = extra; extra += ncell; --ncopies; }
+        else { binning = false; binning_on = false; }      // no room: per-step atomics
+    }
+    if (hist_t) SSRS_HIP_CHECK(hipMemsetAsync(hist_t, 0, sizeof(uint32_t) * ncell, st));
+    a.vis_r = hist_t ? 1u : static_cast<uint32_t>(p->cols);
+    a.vis_c = hist_t ? static_cast<uint32_t>(p->rows) : 1u;
     ncopies = ncopies > 64 ? 64 : ncopies;
-    uint32_t *copies_ptr = ncopies >= 2 ? reinterpret_cast<uint32_t *>(static_cast<char *>(workspace) + ws_base) : nullptr;
+    uint32_t *copies_ptr = ncopies >= 2 ? extra : nullptr;
     bool copies_live = false;
     a.hist_copies = nullptr;
     a.ncopies = 1;
@@ -1665,8 +1706,12 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
             if (binning_on) {
                 hipEvent_t b0 = nullptr, b1 = nullptr;
                 if (profile && hipEventCreate(&b0) == hipSuccess) (void)hipEventRecord(b0, st);
-                hipLaunchKernelGGL(k_bin_visits, dim3(S), dim3(kBinThreads), 0, st, ws.visits, ws.visit_stride,
-                                   ws.ctl, launch & 3, hist, p->rows, p->cols, ws.cap);
+                if (hist_t)
+                    hipLaunchKernelGGL(k_bin_visits, dim3(S), dim3(kBinThreads), 0, st, ws.visits, ws.visit_stride,
+                                       ws.ctl, launch & 3, hist_t, p->cols, p->rows, ws.cap);
+                else
+                    hipLaunchKernelGGL(k_bin_visits, dim3(S), dim3(kBinThreads), 0, st, ws.visits, ws.visit_stride,
+                                       ws.ctl, launch & 3, hist, p->rows, p->cols, ws.cap);
                 if (profile && b0 && hipEventCreate(&b1) == hipSuccess) {
                     (void)hipEventRecord(b1, st);
                     ev_hist.push_back(b0);
@@ -1720,6 +1765,9 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
     }
     if (copies_live && rc == SSRS_OK)
         hipLaunchKernelGGL(k_fold_copies, dim3(4096), dim3(kBlock), 0, st, copies_ptr, ncopies, ncell, hist);
+    if (hist_t && rc == SSRS_OK)
+        hipLaunchKernelGGL(k_transpose_add, dim3(static_cast<unsigned>(((p->rows + 31) / 32) * ((p->cols + 31) / 32))),
+                           dim3(kBlock), 0, st, hist_t, p->rows, p->cols, hist);
     if (profile) {
         hipEvent_t e;
         if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); ev_prof.push_back(e); }

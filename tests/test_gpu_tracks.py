@@ -501,3 +501,37 @@ def test_no_histogram_requested(gpu):
         assert res.hist is None
         assert np.array_equal(res.lengths.cpu().numpy(), ref['lengths']), kw
         assert np.array_equal(res.ends.cpu().numpy(), ref['ends']), kw
+
+
+@pytest.mark.parametrize('dirn', [90., 270., 0., 45.])
+def test_binned_histogram_for_every_heading(gpu, dirn):
+    """East / west batches bin into a transposed histogram (their front is a column);
+    north / south into the plain one; diagonal fronts fall back to atomics.  Large enough
+    (>= 8192 tracks, starts at the upstream edge) for the binning path to be taken."""
+    from ssrs_amd import movmodel
+    from oracle import c_oracle
+    rows, cols = 260, 330
+    upd, _ = _random_field_case(rows, cols, 41)
+    th = np.deg2rad(dirn)
+    rr = np.arange(rows)[:, None]; cc = np.arange(cols)[None, :]
+    along = rr * np.cos(th) + cc * np.sin(th)
+    rng = np.random.default_rng(6)
+    pot = (1000. * (1 - (along - along.min()) / (along.max() - along.min())) +
+           rng.normal(0, 0.05, (rows, cols))).astype(np.float32)
+    n = 9000
+    t = rng.integers(2, 12, n)
+    if dirn == 90.:
+        starts = np.stack([rng.integers(0, rows, n), t], 1)
+    elif dirn == 270.:
+        starts = np.stack([rng.integers(0, rows, n), cols - 1 - t], 1)
+    else:
+        starts = np.stack([t, rng.integers(0, cols, n)], 1)
+    ref = c_oracle.simulate_tracks(dirn, starts, (rows, cols), 1, 1., upd, pot, seed=13, want_traj=False)
+    for kw in (dict(ring=True), dict(ring=False)):
+        res = movmodel.simulate_tracks(dirn, starts, (rows, cols), 1, 1., upd, pot, seed=13, use_table=True,
+                                       profile=True, **kw)
+        lens, ends, hist = _no_traj_result(res)
+        assert np.array_equal(lens, ref['lengths']), (dirn, kw)
+        assert np.array_equal(hist, ref['hist']), (dirn, kw)
+        if dirn in (0., 90., 270.):
+            assert res.stats['hist_ms'] > 0.0, 'the binning path was not taken'
