@@ -966,7 +966,8 @@ struct __attribute__((packed, aligned(4))) RingTriple { float x0, x1, x2; };
 // zero-mask byte says the same, and a wandering track reuses its 128-cell line for many
 // steps.  Lanes whose mask bits are not all set gather as usual (one more dependent
 // load, which is why the front-shaped regime does not use this variant).
-template <bool RING, bool ZMASK = false>
+// VT: visit keys of the transposed histogram (east / west fronts), col * rows + row.
+template <bool RING, bool ZMASK = false, bool VT = false>
 __global__ __launch_bounds__(kBlock) void k_step_lean(const StepArgs a)
 {
     TrackCtl *ctl = a.ctl;
@@ -1153,9 +1154,10 @@ __global__ __launch_bounds__(kBlock) void k_step_lean(const StepArgs a)
         // ---- presence histogram (see k_step_tracks)
         const uint32_t cell = __umul24(static_cast<uint32_t>(row), ucols) + static_cast<uint32_t>(col);
         if (a.visits) {
-            a.visits[static_cast<long long>(it) * a.visit_stride + i] =
-                st ? __umul24(static_cast<uint32_t>(row), a.vis_r) + __umul24(static_cast<uint32_t>(col), a.vis_c)
-                   : 0xFFFFFFFFu;
+            const uint32_t key = VT ? __umul24(static_cast<uint32_t>(col), static_cast<uint32_t>(a.rows)) +
+                                          static_cast<uint32_t>(row)
+                                    : cell;
+            a.visits[static_cast<long long>(it) * a.visit_stride + i] = st ? key : 0xFFFFFFFFu;
         } else if (a.hist) {
             uint32_t *h = a.hist;
             // scattered variant: wave-private copy, so that same-address atomics of
@@ -1691,7 +1693,9 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
             switch (mode) {
             case MODE_TABLE:
                 if (ring && scattered && !binning_on) hipLaunchKernelGGL((k_step_lean<true, true>), dim3(blocks), dim3(kBlock), 0, st, a);
+                else if (ring && hist_t) hipLaunchKernelGGL((k_step_lean<true, false, true>), dim3(blocks), dim3(kBlock), 0, st, a);
                 else if (ring) hipLaunchKernelGGL((k_step_lean<true, false>), dim3(blocks), dim3(kBlock), 0, st, a);
+                else if (lean && a.fast && (S & 1) == 0 && hist_t) hipLaunchKernelGGL((k_step_lean<false, false, true>), dim3(blocks), dim3(kBlock), 0, st, a);
                 else if (lean && a.fast && (S & 1) == 0) hipLaunchKernelGGL((k_step_lean<false, false>), dim3(blocks), dim3(kBlock), 0, st, a);
                 else hipLaunchKernelGGL(k_step_tracks<MODE_TABLE>, dim3(blocks), dim3(kBlock), 0, st, a);
                 break;

@@ -10,7 +10,7 @@ dem = torch.from_numpy(synthetic_dem((rows, cols), res)).cuda()
 _, upd = layers.updraft_from_dem(dem, res, 10., 270., threshold=0.75)
 rr = np.arange(rows, dtype=np.float64)[:, None]; cc = np.arange(cols, dtype=np.float64)[None, :]
 rng = np.random.default_rng(30)
-for dirn in (0., 180., 90., 270., 45., 135.):
+for dirn in (0., 90., 45., 135., 30., 250.):
     th = np.deg2rad(dirn)
     along = rr * np.cos(th) + cc * np.sin(th)                 # distance along the heading (north = +row)
     pot = torch.from_numpy((1000. * (1. - (along - along.min()) / (along.max() - along.min()))).astype(np.float32)).cuda()
@@ -21,10 +21,12 @@ for dirn in (0., 180., 90., 270., 45., 135.):
     elif dirn in (90., 270.):
         c = t if dirn == 90. else cols - 1 - t; r = s * rows
     else:
-        # diagonal: start near the upstream corner edges
-        r = np.where(rng.random(n) < 0.5, t, s * rows * 0.5)
-        c = np.where(r == t, s * cols * 0.5, t)
-        if dirn == 135.: r = rows - 1 - r
+        # oblique: start bands along the two upstream edges
+        up_r = t if np.cos(th) > 0 else rows - 1 - t
+        up_c = t if np.sin(th) > 0 else cols - 1 - t
+        pick = rng.random(n) < 0.5
+        r = np.where(pick, up_r, s * rows)
+        c = np.where(pick, s * cols, up_c)
     starts = np.stack([np.clip(r, 1, rows - 2), np.clip(c, 1, cols - 2)], 1).astype(np.int32)
     table = movmodel.build_transition_table(upd, pot, ring=True)
     hist = torch.zeros((rows, cols), dtype=torch.int32, device='cuda')
