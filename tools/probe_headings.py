@@ -10,7 +10,7 @@ dem = torch.from_numpy(synthetic_dem((rows, cols), res)).cuda()
 _, upd = layers.updraft_from_dem(dem, res, 10., 270., threshold=0.75)
 rr = np.arange(rows, dtype=np.float64)[:, None]; cc = np.arange(cols, dtype=np.float64)[None, :]
 rng = np.random.default_rng(30)
-for dirn in (0., 90., 45., 135., 30., 250.):
+for dirn in ([float(v) for v in sys.argv[1:]] or (0., 90., 45., 135., 30., 250.)):
     th = np.deg2rad(dirn)
     along = rr * np.cos(th) + cc * np.sin(th)                 # distance along the heading (north = +row)
     pot = torch.from_numpy((1000. * (1. - (along - along.min()) / (along.max() - along.min()))).astype(np.float32)).cuda()
