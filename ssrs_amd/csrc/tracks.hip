@@ -34,6 +34,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -1340,6 +1341,180 @@ __global__ __launch_bounds__(kBlock) void k_fold_copies(const uint32_t *__restri
     }
 }
 
+// K3 for oblique headings.  There a front diffuses along BOTH raster axes (heading 45 deg:
+// the moves N, NE, E advance 1, 1, 0 rows): a step's visits span hundreds of rows, no
+// per-step row window holds them, and per-visit atomics run at the memory side's ~2e10/s
+// (27 ms per 100k tracks at C2 against 5 ms for axis-aligned headings).  But over one
+// launch the region the front sweeps receives ~8 visits per cell.  So the launch's visits
+// are bucketed by raster TILE (kTileRows x kTileCols cells = 61 440 16-bit LDS counters):
+//   k_tile_sort<false>  counts visits per tile        (one read of the visit buffer)
+//   k_tile_scan         bucket starts
+//   k_tile_sort<true>   copies visits into buckets    (one read, one write)
+//   k_bin_bucket        one block per non-empty tile: LDS counters, row-wise flush
+// 0.8 GB of traffic per launch instead of 5e7 memory-side atomics.  The order inside a
+// bucket is arbitrary; a histogram does not care.  A counter that reaches 0x8000 is
+// emptied by the one thread that saw it (LDS atomics return the old value; at most
+// 1023 x 8 other increments can land in between, so 16 bits never overflow).
+constexpr int kTileThreads = 1024;
+constexpr int kTileRows = 60, kTileCols = 1024;              // 61 440 counters, 120 KB
+constexpr int kTilesMax = 4096;                              // tiles per raster (LDS count array)
+
+__device__ __forceinline__ void split_cell(uint32_t c, uint32_t cols, double inv_cols, uint32_t &r, uint32_t &cc)
+{
+    r = static_cast<uint32_t>(static_cast<double>(c) * inv_cols);          // c < 2^31: off by one at most
+    if (r * cols > c) --r;
+    if ((r + 1u) * cols <= c) ++r;
+    cc = c - r * cols;
+}
+
+__device__ __forceinline__ uint32_t tile_of(uint32_t c, uint32_t cols, double inv_cols, uint32_t ntc)
+{
+    uint32_t r, cc;
+    split_cell(c, cols, inv_cols, r, cc);
+    return (r / kTileRows) * ntc + cc / kTileCols;
+}
+
+// block (x, b): slots [256 b, 256 b + 256) of list x, all steps of the launch.  These are
+// the same 256 tracks step after step, so a block meets a handful of tiles.
+template <bool SCATTER>
+__global__ __launch_bounds__(kBlock) void k_tile_sort(const uint32_t *__restrict__ visits, long long stride, int steps,
+                                                     const TrackCtl *__restrict__ ctl, int slot, uint32_t cols,
+                                                     double inv_cols, uint32_t ncell, uint32_t cap, uint32_t ntc,
+                                                     uint32_t ntiles, uint32_t *__restrict__ tile_count,
+                                                     uint32_t *__restrict__ tile_cursor, uint32_t *__restrict__ bucket)
+{
+    __shared__ uint32_t cnt[kTilesMax];
+    __shared__ uint32_t base[SCATTER ? kTilesMax : 1];
+    const uint32_t x = blockIdx.x % kXcd, j = (blockIdx.x / kXcd) * kBlock + threadIdx.x;
+    const uint32_t nslots = (ctl->count[slot][x] + 63u) & ~63u;
+    if ((blockIdx.x / kXcd) * kBlock >= nslots) return;           // whole block idle
+    for (uint32_t t = threadIdx.x; t < ntiles; t += kBlock) cnt[t] = 0;
+    __syncthreads();
+    const uint32_t *v = visits + static_cast<size_t>(x) * cap + j;
+    constexpr int kU = 8;
+    if (j < nslots) {
+        // a track stays in one tile for many steps: count runs, one LDS atomic per run
+        uint32_t cur = 0xFFFFFFFFu, run = 0;
+        for (int it = 0; it < steps; it += kU) {
+            uint32_t c[kU];
+#pragma unroll
+            for (int q = 0; q < kU; ++q) c[q] = it + q < steps ? v[static_cast<long long>(it + q) * stride] : 0xFFFFFFFFu;
+#pragma unroll
+            for (int q = 0; q < kU; ++q) {
+                if (c[q] >= ncell) continue;
+                const uint32_t t = tile_of(c[q], cols, inv_cols, ntc);
+                if (t != cur) {
+                    if (run) atomicAdd(&cnt[cur], run);
+                    cur = t; run = 0;
+                }
+                ++run;
+            }
+        }
+        if (run) atomicAdd(&cnt[cur], run);
+    }
+    __syncthreads();
+    if (!SCATTER) {
+        for (uint32_t t = threadIdx.x; t < ntiles; t += kBlock)
+            if (cnt[t]) atomicAdd(&tile_count[t], cnt[t]);
+        return;
+    }
+    // reserve this block's share of every bucket it feeds, then copy
+    for (uint32_t t = threadIdx.x; t < ntiles; t += kBlock) {
+        const uint32_t n = cnt[t];
+        if (n) { base[t] = atomicAdd(&tile_cursor[t], n); cnt[t] = 0; }
+    }
+    __syncthreads();
+    if (j >= nslots) return;
+    for (int it = 0; it < steps; it += kU) {
+        uint32_t c[kU];
+#pragma unroll
+        for (int q = 0; q < kU; ++q) c[q] = it + q < steps ? v[static_cast<long long>(it + q) * stride] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int q = 0; q < kU; ++q) {
+            if (c[q] >= ncell) continue;
+            const uint32_t t = tile_of(c[q], cols, inv_cols, ntc);
+            bucket[base[t] + atomicAdd(&cnt[t], 1u)] = c[q];
+        }
+    }
+}
+
+// exclusive scan of the tile counts (<= 4096): bucket starts; the cursors start there
+__global__ __launch_bounds__(kTileThreads) void k_tile_scan(const uint32_t *__restrict__ tile_count, uint32_t ntiles,
+                                                           uint32_t *__restrict__ tile_start,
+                                                           uint32_t *__restrict__ tile_cursor)
+{
+    using Scan = hipcub::BlockScan<uint32_t, kTileThreads>;
+    __shared__ typename Scan::TempStorage tmp;
+    constexpr int kPer = kTilesMax / kTileThreads;
+    uint32_t n[kPer], sum = 0, prefix;
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+        const uint32_t t = threadIdx.x * kPer + q;
+        n[q] = t < ntiles ? tile_count[t] : 0u;
+        sum += n[q];
+    }
+    Scan(tmp).ExclusiveSum(sum, prefix);
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+        const uint32_t t = threadIdx.x * kPer + q;
+        if (t < ntiles) { tile_start[t] = prefix; tile_cursor[t] = prefix; }
+        prefix += n[q];
+    }
+}
+
+__global__ __launch_bounds__(kTileThreads) void k_bin_bucket(const uint32_t *__restrict__ bucket,
+                                                            const uint32_t *__restrict__ tile_start,
+                                                            const uint32_t *__restrict__ tile_count,
+                                                            TrackCtl *__restrict__ ctl, uint32_t *__restrict__ hist,
+                                                            uint32_t rows, uint32_t cols, double inv_cols, uint32_t ntc)
+{
+    __shared__ uint32_t bins[kTileRows * kTileCols / 2];
+    const uint32_t n = tile_count[blockIdx.x];
+    if (n == 0) return;
+    const uint32_t r0 = (blockIdx.x / ntc) * kTileRows, c0 = (blockIdx.x % ntc) * kTileCols;
+    const uint32_t *b = bucket + tile_start[blockIdx.x];
+    for (int k = threadIdx.x; k < kTileRows * kTileCols / 2; k += kTileThreads) bins[k] = 0;
+    __syncthreads();
+    constexpr int kU = 8;
+    for (uint32_t i = threadIdx.x; i < n; i += kTileThreads * kU) {
+        uint32_t c[kU];
+#pragma unroll
+        for (int q = 0; q < kU; ++q) {
+            const uint32_t ii = i + q * kTileThreads;
+            c[q] = ii < n ? b[ii] : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int q = 0; q < kU; ++q) {
+            if (c[q] == 0xFFFFFFFFu) continue;
+            uint32_t r, cc;
+            split_cell(c[q], cols, inv_cols, r, cc);
+            const uint32_t idx = (r - r0) * kTileCols + (cc - c0), sh = (idx & 1u) * 16u;
+            const uint32_t old = atomicAdd(&bins[idx >> 1], 1u << sh);
+            if (((old >> sh) & 0xFFFFu) == 0x8000u) {            // this thread empties the counter
+                atomicAdd(&hist[c[q]], 0x8001u);
+                atomicSub(&bins[idx >> 1], 0x8001u << sh);
+            }
+        }
+    }
+    __syncthreads();
+    // flush: consecutive lanes, consecutive cells.  The number of cells flushed tells the
+    // host whether bucketing still pays (strays = cells; it stops below 2 visits per cell).
+    uint32_t flushed = 0;
+    const uint32_t trows = rows - r0 < kTileRows ? rows - r0 : kTileRows;
+    const uint32_t tcols = cols - c0 < kTileCols ? cols - c0 : kTileCols;
+    for (uint32_t w = threadIdx.x; w < trows * (kTileCols / 2); w += kTileThreads) {
+        const uint32_t pair = bins[w];
+        if (!pair) continue;
+        const uint32_t dr = w / (kTileCols / 2), dc = 2 * (w % (kTileCols / 2));
+        uint32_t *h = hist + static_cast<size_t>(r0 + dr) * cols + c0 + dc;
+        if (pair & 0xFFFFu) { atomicAdd(h, pair & 0xFFFFu); ++flushed; }
+        if ((pair >> 16) && dc + 1 < tcols) { atomicAdd(h + 1, pair >> 16); ++flushed; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) flushed += __shfl_down(flushed, off);
+    if ((threadIdx.x & 63) == 0 && flushed) atomicAdd(&ctl->strays, static_cast<unsigned long long>(flushed));
+}
+
 // hist (rows x cols) += transpose of hist_t (cols x rows): the transposed histogram that
 // east / west batches bin into (there a step's visits fill a few COLUMNS, which are rows
 // of hist_t, so the LDS window of k_bin_visits and its contiguous flush work unchanged)
@@ -1372,6 +1547,8 @@ struct Workspace {
     unsigned long long *keys[2];
     void *sort_temp;
     size_t sort_temp_bytes;
+    uint32_t *bucket;            // the same visits ordered by raster tile (oblique headings)
+    uint32_t *tile_count, *tile_start, *tile_cursor;   // [kTilesMax] each
     uint32_t *visits;            // [kVisitSteps][visit_stride] visited cells of one launch
     long long visit_stride;
     uint32_t cap;                // slots per XCD list
@@ -1418,6 +1595,14 @@ static size_t workspace_layout(int64_t n, char *base, Workspace *ws)
     // (a second buffer would only be needed to overlap it with the next launch)
     if (ws) { ws->visits = reinterpret_cast<uint32_t *>(base + off); ws->visit_stride = stride; }
     off = align_up(off + sizeof(uint32_t) * static_cast<size_t>(stride) * kVisitSteps, 256);
+    if (ws) ws->bucket = reinterpret_cast<uint32_t *>(base + off);
+    off = align_up(off + sizeof(uint32_t) * static_cast<size_t>(stride) * kVisitSteps, 256);
+    if (ws) {
+        ws->tile_count = reinterpret_cast<uint32_t *>(base + off);
+        ws->tile_start = ws->tile_count + kTilesMax;
+        ws->tile_cursor = ws->tile_start + kTilesMax;
+    }
+    off = align_up(off + 3 * sizeof(uint32_t) * kTilesMax, 256);
     return off;
 }
 
@@ -1619,18 +1804,25 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
     // binning 1.4 -> 3.5 ms; profiles/r01_notes.md).
     // east / west headings: the front is a column, so the batch bins into a TRANSPOSED
     // histogram (needs one raster of extra workspace, see below)
-    const bool want_transposed = coherent && std::fabs(geom.sin_t) > std::fabs(geom.cos_t);
+    // oblique headings: visits bucketed by raster tile (k_tile_sort / k_bin_bucket)
+    const double off_axis = std::fabs(geom.sin_t) < std::fabs(geom.cos_t) ? std::fabs(geom.sin_t) : std::fabs(geom.cos_t);
+    const uint32_t ntc = static_cast<uint32_t>((p->cols + kTileCols - 1) / kTileCols);
+    const uint32_t ntiles = ntc * static_cast<uint32_t>((p->rows + kTileRows - 1) / kTileRows);
+    const bool tiles_ok = hist != nullptr && coherent && S <= kVisitSteps && ntracks >= 8192 && ntiles <= kTilesMax &&
+                          (p->flags & SSRS_TRACKS_NO_BINNING) == 0 && std::getenv("SSRS_TRACKS_NO_TILES") == nullptr;
+    bool tiles_on = tiles_ok && off_axis > 0.17;                 // more than ~10 degrees off a raster axis
+    const bool want_transposed = coherent && !tiles_on && std::fabs(geom.sin_t) > std::fabs(geom.cos_t);
     bool binning = hist != nullptr && coherent && S <= kVisitSteps &&
                    (p->flags & SSRS_TRACKS_NO_BINNING) == 0 &&
                    (want_transposed ? p->rows : p->cols) <= kBinCells;
     a.visits = nullptr;
     a.visit_stride = ws.visit_stride;
-    bool binning_on = binning && ntracks >= 8192;   // small batches: plain atomics are cheaper
+    bool binning_on = binning && ntracks >= 8192 && !tiles_on;   // small batches: plain atomics are cheaper
     // SSRS_TRACKS_SCATTERED forces the zero-mask variant from the first launch,
     // SSRS_TRACKS_NO_SCATTERED keeps it off (A/B switches; results are identical)
     const bool never_scattered = (p->flags & SSRS_TRACKS_NO_SCATTERED) != 0;
     bool scattered = (p->flags & SSRS_TRACKS_SCATTERED) != 0;
-    if (scattered) binning_on = false;
+    if (scattered) binning_on = tiles_on = false;
     // private histogram copies live behind the regular workspace when the caller gave room
     const size_t ncell = static_cast<size_t>(p->rows) * static_cast<size_t>(p->cols);
     const size_t ws_base = align_up(ssrs_tracks_workspace_bytes(ntracks), 256);
@@ -1685,14 +1877,14 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
                 a.hist_copies = copies_ptr;
                 a.ncopies = ncopies;
             }
-            if (binning_on) a.visits = ws.visits;
+            if (binning_on || tiles_on) a.visits = ws.visits;
             if (profile) {
                 hipEvent_t e;
                 if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); ev_prof.push_back(e); }
             }
             switch (mode) {
             case MODE_TABLE:
-                if (ring && scattered && !binning_on) hipLaunchKernelGGL((k_step_lean<true, true>), dim3(blocks), dim3(kBlock), 0, st, a);
+                if (ring && scattered && !binning_on && !tiles_on) hipLaunchKernelGGL((k_step_lean<true, true>), dim3(blocks), dim3(kBlock), 0, st, a);
                 else if (ring && hist_t) hipLaunchKernelGGL((k_step_lean<true, false, true>), dim3(blocks), dim3(kBlock), 0, st, a);
                 else if (ring) hipLaunchKernelGGL((k_step_lean<true, false>), dim3(blocks), dim3(kBlock), 0, st, a);
                 else if (lean && a.fast && (S & 1) == 0 && hist_t) hipLaunchKernelGGL((k_step_lean<false, false, true>), dim3(blocks), dim3(kBlock), 0, st, a);
@@ -1716,6 +1908,28 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
                 else
                     hipLaunchKernelGGL(k_bin_visits, dim3(S), dim3(kBinThreads), 0, st, ws.visits, ws.visit_stride,
                                        ws.ctl, launch & 3, hist, p->rows, p->cols, ws.cap);
+                if (profile && b0 && hipEventCreate(&b1) == hipSuccess) {
+                    (void)hipEventRecord(b1, st);
+                    ev_hist.push_back(b0);
+                    ev_hist.push_back(b1);
+                }
+            }
+            if (tiles_on) {
+                hipEvent_t b0 = nullptr, b1 = nullptr;
+                if (profile && hipEventCreate(&b0) == hipSuccess) (void)hipEventRecord(b0, st);
+                const double inv_cols = 1.0 / static_cast<double>(p->cols);
+                const uint32_t ucols = static_cast<uint32_t>(p->cols), ucell = static_cast<uint32_t>(ncell);
+                (void)hipMemsetAsync(ws.tile_count, 0, sizeof(uint32_t) * ntiles, st);
+                hipLaunchKernelGGL((k_tile_sort<false>), dim3(blocks), dim3(kBlock), 0, st, ws.visits, ws.visit_stride, S,
+                                   ws.ctl, launch & 3, ucols, inv_cols, ucell, ws.cap, ntc, ntiles, ws.tile_count,
+                                   ws.tile_cursor, ws.bucket);
+                hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(kTileThreads), 0, st, ws.tile_count, ntiles, ws.tile_start,
+                                   ws.tile_cursor);
+                hipLaunchKernelGGL((k_tile_sort<true>), dim3(blocks), dim3(kBlock), 0, st, ws.visits, ws.visit_stride, S,
+                                   ws.ctl, launch & 3, ucols, inv_cols, ucell, ws.cap, ntc, ntiles, ws.tile_count,
+                                   ws.tile_cursor, ws.bucket);
+                hipLaunchKernelGGL(k_bin_bucket, dim3(ntiles), dim3(kTileThreads), 0, st, ws.bucket, ws.tile_start,
+                                   ws.tile_count, ws.ctl, hist, static_cast<uint32_t>(p->rows), ucols, inv_cols, ntc);
                 if (profile && b0 && hipEventCreate(&b1) == hipSuccess) {
                     (void)hipEventRecord(b1, st);
                     ev_hist.push_back(b0);
@@ -1751,16 +1965,24 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
             // binning pays only while the batch moves as a front: once more than a
             // quarter of a batch's visits miss the LDS window, later launches go back
             // to in-stepper atomics
-            if (binning_on) {
+            if (binning_on || tiles_on) {
+                // row window: strays = visits outside it (stop above a quarter); tiles:
+                // strays = cells flushed (stop below two visits per cell)
                 const unsigned long long dsteps = tot[0] - seen_steps, dstray = tot[1] - seen_strays;
-                if (dsteps > 0 && dstray * 4 > dsteps) {
-                    binning_on = false;
-                    scattered = !never_scattered;          // no front any more: zero-mask variant
+                if (dsteps > 0 && dstray * (tiles_on ? 2 : 4) > dsteps) {
+                    if (binning_on && tiles_ok && !hist_t) {
+                        // the front has outgrown the row window; its visits may still cluster
+                        binning_on = false;
+                        tiles_on = true;
+                    } else {
+                        binning_on = tiles_on = false;
+                        scattered = !never_scattered;      // no front any more: zero-mask variant
+                    }
                 }
             }
             // batches that never binned (small, unsorted, very wide rasters) give no stray
             // signal: tracks still alive after four raster crossings are wandering
-            if (!binning_on && !scattered && !never_scattered &&
+            if (!binning_on && !tiles_on && !scattered && !never_scattered &&
                 static_cast<long long>(launch) * S > 4ll * (p->rows + p->cols))
                 scattered = true;
             seen_steps = tot[0];

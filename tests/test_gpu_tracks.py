@@ -503,11 +503,12 @@ def test_no_histogram_requested(gpu):
         assert np.array_equal(res.ends.cpu().numpy(), ref['ends']), kw
 
 
-@pytest.mark.parametrize('dirn', [90., 270., 0., 45.])
+@pytest.mark.parametrize('dirn', [90., 270., 0., 45., 135., 200., 30.])
 def test_binned_histogram_for_every_heading(gpu, dirn):
     """East / west batches bin into a transposed histogram (their front is a column);
-    north / south into the plain one; diagonal fronts fall back to atomics.  Large enough
-    (>= 8192 tracks, starts at the upstream edge) for the binning path to be taken."""
+    north / south into the plain one; oblique fronts through tile buckets (k_tile_sort /
+    k_bin_bucket).  Large enough (>= 8192 tracks, starts at the upstream edge) for the
+    binning paths to be taken."""
     from ssrs_amd import movmodel
     from oracle import c_oracle
     rows, cols = 260, 330
@@ -524,6 +525,8 @@ def test_binned_histogram_for_every_heading(gpu, dirn):
         starts = np.stack([rng.integers(0, rows, n), t], 1)
     elif dirn == 270.:
         starts = np.stack([rng.integers(0, rows, n), cols - 1 - t], 1)
+    elif np.cos(th) < 0:
+        starts = np.stack([rows - 1 - t, rng.integers(0, cols, n)], 1)
     else:
         starts = np.stack([t, rng.integers(0, cols, n)], 1)
     ref = c_oracle.simulate_tracks(dirn, starts, (rows, cols), 1, 1., upd, pot, seed=13, want_traj=False)
@@ -533,5 +536,32 @@ def test_binned_histogram_for_every_heading(gpu, dirn):
         lens, ends, hist = _no_traj_result(res)
         assert np.array_equal(lens, ref['lengths']), (dirn, kw)
         assert np.array_equal(hist, ref['hist']), (dirn, kw)
-        if dirn in (0., 90., 270.):
-            assert res.stats['hist_ms'] > 0.0, 'the binning path was not taken'
+        assert res.stats['hist_ms'] > 0.0, 'the binning path was not taken'
+
+
+@pytest.mark.parametrize('rows,cols,n,dirn,same_start', [(200, 200, 70000, 45., True), (40, 32000, 9000, 60., False),
+                                                         (3000, 1400, 20000, 20., False)])
+def test_tile_binning_corner_cases(gpu, rows, cols, n, dirn, same_start):
+    """Tile-bucketed binning: 16-bit LDS counters that overflow within one launch (70 000
+    tracks from one cell), a raster one tile high and 32 wide, and random starts all over
+    the raster (about two visits per cell and launch: the host leaves the tile path)."""
+    from ssrs_amd import movmodel
+    from oracle import c_oracle
+    upd, _ = _random_field_case(rows, cols, 43)
+    th = np.deg2rad(dirn)
+    rr = np.arange(rows)[:, None]; cc = np.arange(cols)[None, :]
+    along = rr * np.cos(th) + cc * np.sin(th)
+    rng = np.random.default_rng(8)
+    pot = (1000. * (1 - (along - along.min()) / (along.max() - along.min())) +
+           rng.normal(0, 0.05, (rows, cols))).astype(np.float32)
+    if same_start:
+        starts = np.tile(np.array([[3, 3]]), (n, 1))
+    else:
+        starts = np.stack([rng.integers(0, rows, n), rng.integers(0, cols, n)], 1)
+    ref = c_oracle.simulate_tracks(dirn, starts, (rows, cols), 1, 1., upd, pot, seed=21, want_traj=False)
+    res = movmodel.simulate_tracks(dirn, starts, (rows, cols), 1, 1., upd, pot, seed=21, use_table=True, ring=True)
+    lens, ends, hist = _no_traj_result(res)
+    assert np.array_equal(lens, ref['lengths'])
+    assert np.array_equal(hist, ref['hist'])
+    if same_start:
+        assert int(ref['hist'].max()) > 0x8000
