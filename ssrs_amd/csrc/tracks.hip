@@ -1346,7 +1346,7 @@ __global__ __launch_bounds__(kBlock) void k_fold_copies(const uint32_t *__restri
 // per-step row window holds them, and per-visit atomics run at the memory side's ~2e10/s
 // (27 ms per 100k tracks at C2 against 5 ms for axis-aligned headings).  But over one
 // launch the region the front sweeps receives ~8 visits per cell.  So the launch's visits
-// are bucketed by raster TILE (kTileRows x kTileCols cells = 61 440 16-bit LDS counters):
+// are bucketed by raster TILE (kTileRows x kTileCols cells = 30 720 16-bit LDS counters):
 //   k_tile_sort<false>  counts visits per tile        (one read of the visit buffer)
 //   k_tile_scan         bucket starts
 //   k_tile_sort<true>   copies visits into buckets    (one read, one write)
@@ -1354,10 +1354,11 @@ __global__ __launch_bounds__(kBlock) void k_fold_copies(const uint32_t *__restri
 // 0.8 GB of traffic per launch instead of 5e7 memory-side atomics.  The order inside a
 // bucket is arbitrary; a histogram does not care.  A counter that reaches 0x8000 is
 // emptied by the one thread that saw it (LDS atomics return the old value; at most
-// 1023 x 8 other increments can land in between, so 16 bits never overflow).
+// 1023 x 16 other increments can land in between, so 16 bits never overflow).
 constexpr int kTileThreads = 1024;
-constexpr int kTileRows = 60, kTileCols = 1024;              // 61 440 counters, 120 KB
+constexpr int kTileRows = 30, kTileCols = 1024;              // 30 720 counters, 60 KB: two blocks per CU
 constexpr int kTilesMax = 4096;                              // tiles per raster (LDS count array)
+constexpr int kBucketSplit = 4;                              // blocks sharing a busy tile
 
 __device__ __forceinline__ void split_cell(uint32_t c, uint32_t cols, double inv_cols, uint32_t &r, uint32_t &cc)
 {
@@ -1374,8 +1375,10 @@ __device__ __forceinline__ uint32_t tile_of(uint32_t c, uint32_t cols, double in
     return (r / kTileRows) * ntc + cc / kTileCols;
 }
 
-// block (x, b): slots [256 b, 256 b + 256) of list x, all steps of the launch.  These are
-// the same 256 tracks step after step, so a block meets a handful of tiles.
+// block (x, b; y): slots [256 b, 256 b + 256) of list x, the y-th of kStepSplit runs of
+// steps (the kernel is bound by load latency: 100k lanes alone cannot cover it).  These
+// are the same 256 tracks step after step, so a block meets a handful of tiles.
+constexpr int kStepSplit = 16;
 template <bool SCATTER>
 __global__ __launch_bounds__(kBlock) void k_tile_sort(const uint32_t *__restrict__ visits, long long stride, int steps,
                                                      const TrackCtl *__restrict__ ctl, int slot, uint32_t cols,
@@ -1392,10 +1395,41 @@ __global__ __launch_bounds__(kBlock) void k_tile_sort(const uint32_t *__restrict
     __syncthreads();
     const uint32_t *v = visits + static_cast<size_t>(x) * cap + j;
     constexpr int kU = 8;
+    const int chunk = ((steps + kStepSplit - 1) / kStepSplit + kU - 1) / kU * kU;
+    const int it0 = static_cast<int>(blockIdx.y) * chunk;
+    steps = steps < it0 + chunk ? steps : it0 + chunk;
+    if (!SCATTER) {
+        if (j < nslots) {
+            // a track stays in one tile for many steps: count runs, one LDS atomic per run
+            uint32_t cur = 0xFFFFFFFFu, run = 0;
+            for (int it = it0; it < steps; it += kU) {
+                uint32_t c[kU];
+#pragma unroll
+                for (int q = 0; q < kU; ++q) c[q] = it + q < steps ? v[static_cast<long long>(it + q) * stride] : 0xFFFFFFFFu;
+#pragma unroll
+                for (int q = 0; q < kU; ++q) {
+                    if (c[q] >= ncell) continue;
+                    const uint32_t t = tile_of(c[q], cols, inv_cols, ntc);
+                    if (t != cur) {
+                        if (run) atomicAdd(&cnt[cur], run);
+                        cur = t; run = 0;
+                    }
+                    ++run;
+                }
+            }
+            if (run) atomicAdd(&cnt[cur], run);
+        }
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < ntiles; t += kBlock)
+            if (cnt[t]) atomicAdd(&tile_count[t], cnt[t]);
+        return;
+    }
+    // SCATTER: count again (the reads hit L2 the second time), reserve the block's share of
+    // every bucket it feeds, copy.  (Keeping the run's 64 visits in registers between the two
+    // sweeps was measured slower, 117 -> 153 us: the unrolled body no longer fits the I-cache.)
     if (j < nslots) {
-        // a track stays in one tile for many steps: count runs, one LDS atomic per run
         uint32_t cur = 0xFFFFFFFFu, run = 0;
-        for (int it = 0; it < steps; it += kU) {
+        for (int it = it0; it < steps; it += kU) {
             uint32_t c[kU];
 #pragma unroll
             for (int q = 0; q < kU; ++q) c[q] = it + q < steps ? v[static_cast<long long>(it + q) * stride] : 0xFFFFFFFFu;
@@ -1413,27 +1447,35 @@ __global__ __launch_bounds__(kBlock) void k_tile_sort(const uint32_t *__restrict
         if (run) atomicAdd(&cnt[cur], run);
     }
     __syncthreads();
-    if (!SCATTER) {
-        for (uint32_t t = threadIdx.x; t < ntiles; t += kBlock)
-            if (cnt[t]) atomicAdd(&tile_count[t], cnt[t]);
-        return;
-    }
-    // reserve this block's share of every bucket it feeds, then copy
     for (uint32_t t = threadIdx.x; t < ntiles; t += kBlock) {
         const uint32_t n = cnt[t];
         if (n) { base[t] = atomicAdd(&tile_cursor[t], n); cnt[t] = 0; }
     }
     __syncthreads();
-    if (j >= nslots) return;
-    for (int it = 0; it < steps; it += kU) {
+    if (j >= nslots) return;                                       // whole waves: nslots is a multiple of 64
+    const uint32_t lane = threadIdx.x & 63u;
+    for (int it = it0; it < steps; it += kU) {
         uint32_t c[kU];
 #pragma unroll
         for (int q = 0; q < kU; ++q) c[q] = it + q < steps ? v[static_cast<long long>(it + q) * stride] : 0xFFFFFFFFu;
 #pragma unroll
         for (int q = 0; q < kU; ++q) {
-            if (c[q] >= ncell) continue;
-            const uint32_t t = tile_of(c[q], cols, inv_cols, ntc);
-            bucket[base[t] + atomicAdd(&cnt[t], 1u)] = c[q];
+            // a wave's 64 tracks are neighbours: nearly always one tile, then one LDS
+            // atomic for the wave instead of 64 on the same address
+            const bool active = c[q] < ncell;
+            const uint32_t t = active ? tile_of(c[q], cols, inv_cols, ntc) : 0u;
+            const unsigned long long act = __ballot(active);
+            if (act == 0) continue;
+            const int leader = __ffsll(static_cast<long long>(act)) - 1;
+            const uint32_t t0 = __shfl(t, leader);
+            if (__ballot(active && t == t0) == act) {
+                uint32_t first = 0;
+                if (lane == static_cast<uint32_t>(leader)) first = atomicAdd(&cnt[t0], static_cast<uint32_t>(__popcll(act)));
+                first = __shfl(first, leader);
+                if (active) bucket[base[t0] + first + __popcll(act & ((1ull << lane) - 1ull))] = c[q];
+            } else if (active) {
+                bucket[base[t] + atomicAdd(&cnt[t], 1u)] = c[q];
+            }
         }
     }
 }
@@ -1469,13 +1511,23 @@ __global__ __launch_bounds__(kTileThreads) void k_bin_bucket(const uint32_t *__r
                                                             uint32_t rows, uint32_t cols, double inv_cols, uint32_t ntc)
 {
     __shared__ uint32_t bins[kTileRows * kTileCols / 2];
-    const uint32_t n = tile_count[blockIdx.x];
+    // busy tiles (the front's densest rows) are shared by gridDim.y blocks, each with its
+    // own counters: the kernel's duration is that of its busiest tile
+    const uint32_t total = tile_count[blockIdx.x];
+    uint32_t lo = 0, n = total;
+    if (total >= 16384u * gridDim.y) {
+        const uint32_t per = (total + gridDim.y - 1) / gridDim.y;
+        lo = blockIdx.y * per;
+        n = total - lo < per ? total - lo : per;
+    } else if (blockIdx.y != 0) {
+        return;
+    }
     if (n == 0) return;
     const uint32_t r0 = (blockIdx.x / ntc) * kTileRows, c0 = (blockIdx.x % ntc) * kTileCols;
-    const uint32_t *b = bucket + tile_start[blockIdx.x];
+    const uint32_t *b = bucket + tile_start[blockIdx.x] + lo;
     for (int k = threadIdx.x; k < kTileRows * kTileCols / 2; k += kTileThreads) bins[k] = 0;
     __syncthreads();
-    constexpr int kU = 8;
+    constexpr int kU = 16;
     for (uint32_t i = threadIdx.x; i < n; i += kTileThreads * kU) {
         uint32_t c[kU];
 #pragma unroll
@@ -1920,15 +1972,15 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
                 const double inv_cols = 1.0 / static_cast<double>(p->cols);
                 const uint32_t ucols = static_cast<uint32_t>(p->cols), ucell = static_cast<uint32_t>(ncell);
                 (void)hipMemsetAsync(ws.tile_count, 0, sizeof(uint32_t) * ntiles, st);
-                hipLaunchKernelGGL((k_tile_sort<false>), dim3(blocks), dim3(kBlock), 0, st, ws.visits, ws.visit_stride, S,
+                hipLaunchKernelGGL((k_tile_sort<false>), dim3(blocks, kStepSplit), dim3(kBlock), 0, st, ws.visits, ws.visit_stride, S,
                                    ws.ctl, launch & 3, ucols, inv_cols, ucell, ws.cap, ntc, ntiles, ws.tile_count,
                                    ws.tile_cursor, ws.bucket);
                 hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(kTileThreads), 0, st, ws.tile_count, ntiles, ws.tile_start,
                                    ws.tile_cursor);
-                hipLaunchKernelGGL((k_tile_sort<true>), dim3(blocks), dim3(kBlock), 0, st, ws.visits, ws.visit_stride, S,
+                hipLaunchKernelGGL((k_tile_sort<true>), dim3(blocks, kStepSplit), dim3(kBlock), 0, st, ws.visits, ws.visit_stride, S,
                                    ws.ctl, launch & 3, ucols, inv_cols, ucell, ws.cap, ntc, ntiles, ws.tile_count,
                                    ws.tile_cursor, ws.bucket);
-                hipLaunchKernelGGL(k_bin_bucket, dim3(ntiles), dim3(kTileThreads), 0, st, ws.bucket, ws.tile_start,
+                hipLaunchKernelGGL(k_bin_bucket, dim3(ntiles, kBucketSplit), dim3(kTileThreads), 0, st, ws.bucket, ws.tile_start,
                                    ws.tile_count, ws.ctl, hist, static_cast<uint32_t>(p->rows), ucols, inv_cols, ntc);
                 if (profile && b0 && hipEventCreate(&b1) == hipSuccess) {
                     (void)hipEventRecord(b1, st);
