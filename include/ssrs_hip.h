@@ -206,7 +206,9 @@ size_t ssrs_transition_ring_bytes(int rows, int cols);
 int ssrs_transition_ring_build(const double *updraft, const float *potential, float *ring,
                                int rows, int cols, void *stream);
 
-/* Bytes of device scratch ssrs_tracks_simulate needs for `ntracks`. */
+/* Bytes of device scratch ssrs_tracks_simulate needs for `ntracks` (about 4.2 KB per
+ * track: two buffers of 512 steps x 4 B for the launch's visited cells, in slot and in
+ * raster-tile order). */
 size_t ssrs_tracks_workspace_bytes(int64_t ntracks);
 /* The same plus room for `hist_copies` (2..64) private copies of the histogram.  A
  * workspace of this size lets ssrs_tracks_simulate privatise the histogram once a batch

@@ -5,7 +5,7 @@
 //   ssrs/movmodel.py:205-217  move_away_from_boundary     -> nudge in step loop
 //   ssrs/movmodel.py:220-244  generate_move_probabilities -> choose_move()
 //   ssrs/movmodel.py:264-318  generate_simulated_tracks   -> k_step_lean, k_step_tracks
-//   ssrs/movmodel.py:410-419  compute_presence_counts     -> k_bin_visits / uint32 atomics
+//   ssrs/movmodel.py:410-419  compute_presence_counts     -> k_bin_visits, k_bin_bucket / uint32 atomics
 //   numpy mtrand `choice`     cumsum, /last, searchsorted 'right'
 //
 // Structure (MI355X-first, not a port of the per-track python loop):
@@ -25,8 +25,10 @@
 //     the flat kernel k_step_lean, whose guarded decision hands near-ties to the
 //     exact sequence (three tiers, see choose_three_ring_f32).
 //   * tracks live in one list per XCD (column bands stay in one L2); the histogram is
-//     a visit buffer + LDS binning kernel while the batch moves as a front, and
-//     wave-private histogram copies once it has scattered (k_fold_copies).
+//     a visit buffer + LDS binning kernel while the batch moves as a front (a row /
+//     column window per step for axis-aligned headings, k_bin_visits; tile buckets per
+//     launch for oblique ones, k_tile_sort + k_bin_bucket), and wave-private histogram
+//     copies once it has scattered (k_fold_copies).
 //   * the move decision reproduces the reference's f64 operation order exactly
 //     (pairwise-8 sums, sequential cumsum, f32 potential differences); built
 //     with -ffp-contract=off so no multiply-add is fused.
