@@ -1360,7 +1360,7 @@ __global__ __launch_bounds__(kBlock) void k_fold_copies(const uint32_t *__restri
 constexpr int kTileThreads = 1024;
 constexpr int kTileRows = 30, kTileCols = 1024;              // 30 720 counters, 60 KB: two blocks per CU
 constexpr int kTilesMax = 4096;                              // tiles per raster (LDS count array)
-constexpr int kBucketSplit = 4;                              // blocks sharing a busy tile
+constexpr uint32_t kItemVisits = 65536;                       // visits per k_bin_bucket block
 
 __device__ __forceinline__ void split_cell(uint32_t c, uint32_t cols, double inv_cols, uint32_t &r, uint32_t &cc)
 {
@@ -1485,48 +1485,53 @@ __global__ __launch_bounds__(kBlock) void k_tile_sort(const uint32_t *__restrict
 // exclusive scan of the tile counts (<= 4096): bucket starts; the cursors start there
 __global__ __launch_bounds__(kTileThreads) void k_tile_scan(const uint32_t *__restrict__ tile_count, uint32_t ntiles,
                                                            uint32_t *__restrict__ tile_start,
-                                                           uint32_t *__restrict__ tile_cursor)
+                                                           uint32_t *__restrict__ tile_cursor,
+                                                           uint32_t *__restrict__ item_start)
 {
     using Scan = hipcub::BlockScan<uint32_t, kTileThreads>;
     __shared__ typename Scan::TempStorage tmp;
     constexpr int kPer = kTilesMax / kTileThreads;
-    uint32_t n[kPer], sum = 0, prefix;
+    uint32_t n[kPer], sum = 0, items = 0, prefix, iprefix;
 #pragma unroll
     for (int q = 0; q < kPer; ++q) {
         const uint32_t t = threadIdx.x * kPer + q;
         n[q] = t < ntiles ? tile_count[t] : 0u;
         sum += n[q];
+        items += (n[q] + kItemVisits - 1) / kItemVisits;
     }
     Scan(tmp).ExclusiveSum(sum, prefix);
+    __syncthreads();
+    Scan(tmp).ExclusiveSum(items, iprefix);
 #pragma unroll
     for (int q = 0; q < kPer; ++q) {
         const uint32_t t = threadIdx.x * kPer + q;
-        if (t < ntiles) { tile_start[t] = prefix; tile_cursor[t] = prefix; }
+        if (t < ntiles) { tile_start[t] = prefix; tile_cursor[t] = prefix; item_start[t] = iprefix; }
         prefix += n[q];
+        iprefix += (n[q] + kItemVisits - 1) / kItemVisits;
     }
+    if (threadIdx.x == kTileThreads - 1) item_start[ntiles] = iprefix;     // the last thread holds the total
 }
 
 __global__ __launch_bounds__(kTileThreads) void k_bin_bucket(const uint32_t *__restrict__ bucket,
                                                             const uint32_t *__restrict__ tile_start,
                                                             const uint32_t *__restrict__ tile_count,
                                                             TrackCtl *__restrict__ ctl, uint32_t *__restrict__ hist,
-                                                            uint32_t rows, uint32_t cols, double inv_cols, uint32_t ntc)
+                                                            uint32_t rows, uint32_t cols, double inv_cols, uint32_t ntc,
+                                                            uint32_t ntiles, const uint32_t *__restrict__ item_start)
 {
     __shared__ uint32_t bins[kTileRows * kTileCols / 2];
-    // busy tiles (the front's densest rows) are shared by gridDim.y blocks, each with its
-    // own counters: the kernel's duration is that of its busiest tile
-    const uint32_t total = tile_count[blockIdx.x];
-    uint32_t lo = 0, n = total;
-    if (total >= 16384u * gridDim.y) {
-        const uint32_t per = (total + gridDim.y - 1) / gridDim.y;
-        lo = blockIdx.y * per;
-        n = total - lo < per ? total - lo : per;
-    } else if (blockIdx.y != 0) {
-        return;
-    }
-    if (n == 0) return;
-    const uint32_t r0 = (blockIdx.x / ntc) * kTileRows, c0 = (blockIdx.x % ntc) * kTileCols;
-    const uint32_t *b = bucket + tile_start[blockIdx.x] + lo;
+    // work item = up to kItemVisits visits of one tile: busy tiles (the front's densest rows,
+    // the pockets wandering tracks circle in) are shared by as many blocks as they need,
+    // each with its own counters.  Block -> tile by bisection of the item starts.
+    if (blockIdx.x >= item_start[ntiles]) return;
+    uint32_t tile = 0;
+    for (uint32_t step = 2048; step > 0; step >>= 1)             // kTilesMax = 4096 > tile + step
+        if (tile + step < ntiles && item_start[tile + step] <= blockIdx.x) tile += step;
+    const uint32_t lo = (blockIdx.x - item_start[tile]) * kItemVisits;
+    const uint32_t total = tile_count[tile];
+    const uint32_t n = total - lo < kItemVisits ? total - lo : kItemVisits;
+    const uint32_t r0 = (tile / ntc) * kTileRows, c0 = (tile % ntc) * kTileCols;
+    const uint32_t *b = bucket + tile_start[tile] + lo;
     for (int k = threadIdx.x; k < kTileRows * kTileCols / 2; k += kTileThreads) bins[k] = 0;
     __syncthreads();
     constexpr int kU = 16;
@@ -1602,7 +1607,7 @@ struct Workspace {
     void *sort_temp;
     size_t sort_temp_bytes;
     uint32_t *bucket;            // the same visits ordered by raster tile (oblique headings)
-    uint32_t *tile_count, *tile_start, *tile_cursor;   // [kTilesMax] each
+    uint32_t *tile_count, *tile_start, *tile_cursor, *item_start;   // [kTilesMax] each, item_start one more
     uint32_t *visits;            // [kVisitSteps][visit_stride] visited cells of one launch
     long long visit_stride;
     uint32_t cap;                // slots per XCD list
@@ -1655,8 +1660,9 @@ static size_t workspace_layout(int64_t n, char *base, Workspace *ws)
         ws->tile_count = reinterpret_cast<uint32_t *>(base + off);
         ws->tile_start = ws->tile_count + kTilesMax;
         ws->tile_cursor = ws->tile_start + kTilesMax;
+        ws->item_start = ws->tile_cursor + kTilesMax;
     }
-    off = align_up(off + 3 * sizeof(uint32_t) * kTilesMax, 256);
+    off = align_up(off + sizeof(uint32_t) * (4 * kTilesMax + 1), 256);
     return off;
 }
 
@@ -1864,7 +1870,8 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
     const uint32_t ntiles = ntc * static_cast<uint32_t>((p->rows + kTileRows - 1) / kTileRows);
     const bool tiles_ok = hist != nullptr && coherent && S <= kVisitSteps && ntracks >= 8192 && ntiles <= kTilesMax &&
                           (p->flags & SSRS_TRACKS_NO_BINNING) == 0 && std::getenv("SSRS_TRACKS_NO_TILES") == nullptr;
-    bool tiles_on = tiles_ok && off_axis > 0.17;                 // more than ~10 degrees off a raster axis
+    const bool force_tiles = tiles_ok && std::getenv("SSRS_TRACKS_FORCE_TILES") != nullptr;   // A/B switch
+    bool tiles_on = tiles_ok && (off_axis > 0.17 || force_tiles);   // more than ~10 degrees off a raster axis
     const bool want_transposed = coherent && !tiles_on && std::fabs(geom.sin_t) > std::fabs(geom.cos_t);
     bool binning = hist != nullptr && coherent && S <= kVisitSteps &&
                    (p->flags & SSRS_TRACKS_NO_BINNING) == 0 &&
@@ -1909,7 +1916,7 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
     int launch = 0;
     // bound on the longest XCD list
     uint32_t upper = static_cast<uint32_t>(ntracks < static_cast<int64_t>(ws.cap) ? ntracks : ws.cap);
-    int batches = 0, checked = 0;
+    int batches = 0, checked = 0, judge_from = 0;
     bool finished = false;
     int rc = SSRS_OK;
     // Termination: every live track either finishes or takes S moves per
@@ -1978,12 +1985,16 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
                                    ws.ctl, launch & 3, ucols, inv_cols, ucell, ws.cap, ntc, ntiles, ws.tile_count,
                                    ws.tile_cursor, ws.bucket);
                 hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(kTileThreads), 0, st, ws.tile_count, ntiles, ws.tile_start,
-                                   ws.tile_cursor);
+                                   ws.tile_cursor, ws.item_start);
                 hipLaunchKernelGGL((k_tile_sort<true>), dim3(blocks, kStepSplit), dim3(kBlock), 0, st, ws.visits, ws.visit_stride, S,
                                    ws.ctl, launch & 3, ucols, inv_cols, ucell, ws.cap, ntc, ntiles, ws.tile_count,
                                    ws.tile_cursor, ws.bucket);
-                hipLaunchKernelGGL(k_bin_bucket, dim3(ntiles, kBucketSplit), dim3(kTileThreads), 0, st, ws.bucket, ws.tile_start,
-                                   ws.tile_count, ws.ctl, hist, static_cast<uint32_t>(p->rows), ucols, inv_cols, ntc);
+                // at most S visits per slot of the launch, and one partly filled item per tile
+                const unsigned long long max_visits = static_cast<unsigned long long>(blocks) * kBlock * S;
+                const unsigned items = static_cast<unsigned>(max_visits / kItemVisits) + ntiles;
+                hipLaunchKernelGGL(k_bin_bucket, dim3(items), dim3(kTileThreads), 0, st, ws.bucket, ws.tile_start,
+                                   ws.tile_count, ws.ctl, hist, static_cast<uint32_t>(p->rows), ucols, inv_cols, ntc,
+                                   ntiles, ws.item_start);
                 if (profile && b0 && hipEventCreate(&b1) == hipSuccess) {
                     (void)hipEventRecord(b1, st);
                     ev_hist.push_back(b0);
@@ -2022,8 +2033,10 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
             if (binning_on || tiles_on) {
                 // row window: strays = visits outside it (stop above a quarter); tiles:
                 // strays = cells flushed (stop below two visits per cell)
+                // (batches queued before a switch still report the old path's strays)
                 const unsigned long long dsteps = tot[0] - seen_steps, dstray = tot[1] - seen_strays;
-                if (dsteps > 0 && dstray * (tiles_on ? 2 : 4) > dsteps) {
+                if (checked - 1 >= judge_from && dsteps > 0 && dstray * (tiles_on ? 2 : 4) > dsteps && !force_tiles) {
+                    judge_from = batches;
                     if (binning_on && tiles_ok && !hist_t) {
                         // the front has outgrown the row window; its visits may still cluster
                         binning_on = false;

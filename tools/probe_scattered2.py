@@ -19,7 +19,7 @@ np.random.seed(30)
 r, c = movmodel.get_starting_indices(n, (5, 55, 1, 2), 'random', (60., 50.), 10.)
 starts = np.stack([r, c], 1)
 table = movmodel.build_transition_table(upd, pot, ring=True)
-for name, kw in (("in-stepper atomics", dict(scattered=False)), ("private copies + zero mask", dict(scattered=True)),
+for name, kw in (("auto (window -> tiles -> copies)", dict()), ("private copies + zero mask", dict(scattered=True)),
                  ('no histogram', dict(scattered=False, want_hist=False))):
     torch.cuda.synchronize(); t = time.time()
     out = movmodel.simulate_tracks(0., starts, shape, 1, 1., upd, pot, seed=30, table=table, profile=True, max_moves=cap, **kw)
@@ -29,4 +29,4 @@ for name, kw in (("in-stepper atomics", dict(scattered=False)), ("private copies
         h = out.hist
         print(f'   histogram: {int(h.sum().item()):.3e} visits in {int((h > 0).sum().item()):.3e} distinct cells, max count {int(h.max().item())}', flush=True)
     print(f'{name:32s} steps {out.stats["total_steps"]:.3e} mean {L.mean():.0f} max {L.max()} launches {out.stats["launches"]} '
-          f'wall {dt:.2f} s  {out.stats["total_steps"] / dt / 1e9:.2f} G steps/s', flush=True)
+          f'wall {dt:.2f} s  {out.stats["total_steps"] / dt / 1e9:.2f} G steps/s  (stepper {out.stats["kernel_ms"]:.1f} ms, binning {out.stats["hist_ms"]:.1f} ms)', flush=True)
