@@ -163,12 +163,13 @@ typedef struct SsrsTrackParams {
                                     for the exact decision of near-ties, memory_parameter 1,
                                     scaling_parameter 1, traj NULL, even steps_per_launch */
 #define SSRS_TRACKS_SCATTERED 32    /* treat the batch as scattered from the first launch: the
-                                      histogram is counted by the de-duplicating per-track kernel
-                                      (tracks that circle in a pocket of the field cost a few
-                                      atomics per launch, not one per step) and the ring stepper
-                                      reads the per-cell zero-mask byte before gathering.  Default:
-                                      switched on when the batch stops moving as a front.  Results
-                                      are identical */
+                                      stepper counts visits itself, into wave-private copies of the
+                                      histogram when the workspace has room for them (tracks that
+                                      circle in a pocket of the field otherwise queue up on single
+                                      cells), and the ring stepper reads the per-cell zero-mask
+                                      byte before gathering.  Default: large batches go from the
+                                      per-step window to tile buckets and only then to this
+                                      variant; small ones directly.  Results are identical */
 #define SSRS_TRACKS_NO_SCATTERED 64 /* never switch to that variant (A/B) */
 #define SSRS_TRACKS_EXACT_ONLY 2 /* disable the guarded division-free decision
                                    (A/B switch; results are identical) */
@@ -179,6 +180,10 @@ typedef struct SsrsTrackStats {
     float kernel_ms;     /* sum of stepper launch durations (SSRS_TRACKS_PROFILE) */
     float wall_ms;       /* first launch -> last completion, HIP events */
     float hist_ms;       /* sum of histogram-binning launch durations (PROFILE) */
+    int32_t window_launches; /* launches whose visits were binned through the per-step row /
+                                column window; */
+    int32_t tile_launches;   /* ... through raster-tile buckets; the other launches counted
+                                in the stepper (atomics on hist or on its private copies) */
 } SsrsTrackStats;
 
 /* Fills rows/cols/burnin/max_moves/memory/nu and zeroes the rest; `prior` must

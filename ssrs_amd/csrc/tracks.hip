@@ -1917,6 +1917,7 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
     // bound on the longest XCD list
     uint32_t upper = static_cast<uint32_t>(ntracks < static_cast<int64_t>(ws.cap) ? ntracks : ws.cap);
     int batches = 0, checked = 0, judge_from = 0;
+    int window_launches = 0, tile_launches = 0;
     bool finished = false;
     int rc = SSRS_OK;
     // Termination: every live track either finishes or takes S moves per
@@ -1948,9 +1949,9 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
                 // (the zero-mask variant only pays under in-stepper atomics: with tile buckets it
                 // was measured slower, 7.0 -> 8.3 s per 100k wandering tracks)
                 if (ring && scattered && !binning_on && !tiles_on) hipLaunchKernelGGL((k_step_lean<true, true>), dim3(blocks), dim3(kBlock), 0, st, a);
-                else if (ring && hist_t) hipLaunchKernelGGL((k_step_lean<true, false, true>), dim3(blocks), dim3(kBlock), 0, st, a);
+                else if (ring && hist_t && binning_on) hipLaunchKernelGGL((k_step_lean<true, false, true>), dim3(blocks), dim3(kBlock), 0, st, a);
                 else if (ring) hipLaunchKernelGGL((k_step_lean<true, false>), dim3(blocks), dim3(kBlock), 0, st, a);
-                else if (lean && a.fast && (S & 1) == 0 && hist_t) hipLaunchKernelGGL((k_step_lean<false, false, true>), dim3(blocks), dim3(kBlock), 0, st, a);
+                else if (lean && a.fast && (S & 1) == 0 && hist_t && binning_on) hipLaunchKernelGGL((k_step_lean<false, false, true>), dim3(blocks), dim3(kBlock), 0, st, a);
                 else if (lean && a.fast && (S & 1) == 0) hipLaunchKernelGGL((k_step_lean<false, false>), dim3(blocks), dim3(kBlock), 0, st, a);
                 else hipLaunchKernelGGL(k_step_tracks<MODE_TABLE>, dim3(blocks), dim3(kBlock), 0, st, a);
                 break;
@@ -1963,6 +1964,7 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
                 if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); ev_bin.push_back(e); }
             }
             if (binning_on) {
+                ++window_launches;
                 hipEvent_t b0 = nullptr, b1 = nullptr;
                 if (profile && hipEventCreate(&b0) == hipSuccess) (void)hipEventRecord(b0, st);
                 if (hist_t)
@@ -1978,6 +1980,7 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
                 }
             }
             if (tiles_on) {
+                ++tile_launches;
                 hipEvent_t b0 = nullptr, b1 = nullptr;
                 if (profile && hipEventCreate(&b0) == hipSuccess) (void)hipEventRecord(b0, st);
                 const double inv_cols = 1.0 / static_cast<double>(p->cols);
@@ -2039,10 +2042,12 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
                 const unsigned long long dsteps = tot[0] - seen_steps, dstray = tot[1] - seen_strays;
                 if (checked - 1 >= judge_from && dsteps > 0 && dstray * (tiles_on ? 2 : 4) > dsteps && !force_tiles) {
                     judge_from = batches;
-                    if (binning_on && tiles_ok && !hist_t) {
+                    if (binning_on && tiles_ok) {
                         // the front has outgrown the row window; its visits may still cluster
                         binning_on = false;
                         tiles_on = true;
+                        a.vis_r = static_cast<uint32_t>(p->cols);      // plain visit keys from now on
+                        a.vis_c = 1u;
                     } else {
                         binning_on = tiles_on = false;
                         scattered = !never_scattered;      // no front any more: zero-mask variant
@@ -2082,6 +2087,8 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
     if (stats && rc == SSRS_OK) {
         stats->total_steps = static_cast<int64_t>(host_ctl.steps);
         stats->launches = launch;
+        stats->window_launches = window_launches;
+        stats->tile_launches = tile_launches;
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, ev_first, ev_last) == hipSuccess) stats->wall_ms = ms;
         if (profile) {

@@ -227,7 +227,8 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
     return TrackBatch(lengths, ends, hist, traj, offsets,
                       dict(total_steps=int(stats.total_steps), launches=int(stats.launches),
                            kernel_ms=float(stats.kernel_ms), wall_ms=float(stats.wall_ms),
-                           hist_ms=float(stats.hist_ms)))
+                           hist_ms=float(stats.hist_ms), window_launches=int(stats.window_launches),
+                           tile_launches=int(stats.tile_launches)))
 
 
 def generate_simulated_tracks(move_dirn, start_location, grid_shape, memory_parameter=1,

@@ -537,6 +537,10 @@ def test_binned_histogram_for_every_heading(gpu, dirn):
         assert np.array_equal(lens, ref['lengths']), (dirn, kw)
         assert np.array_equal(hist, ref['hist']), (dirn, kw)
         assert res.stats['hist_ms'] > 0.0, 'the binning path was not taken'
+        if dirn in (0., 90., 270.):
+            assert res.stats['window_launches'] > 0 and res.stats['tile_launches'] == 0
+        else:
+            assert res.stats['tile_launches'] > 0 and res.stats['window_launches'] == 0
 
 
 @pytest.mark.parametrize('rows,cols,n,dirn,same_start', [(200, 200, 70000, 45., True), (40, 32000, 9000, 60., False),
@@ -563,5 +567,36 @@ def test_tile_binning_corner_cases(gpu, rows, cols, n, dirn, same_start):
     lens, ends, hist = _no_traj_result(res)
     assert np.array_equal(lens, ref['lengths'])
     assert np.array_equal(hist, ref['hist'])
+    assert res.stats['tile_launches'] > 0
     if same_start:
         assert int(ref['hist'].max()) > 0x8000
+
+
+@pytest.mark.parametrize('dirn', [0., 90.])
+def test_wandering_batches_move_from_the_window_to_tile_buckets(gpu, dirn):
+    """A ramp potential with wells wide enough to turn a track around (+-45 degrees per
+    step): a fifth of the tracks circle in a well until max_moves, the row / column window
+    starts missing and the host switches the batch to tile buckets (east / west batches
+    also from transposed to plain visit keys) - same histogram."""
+    from ssrs_amd import movmodel
+    from oracle import c_oracle
+    rows, cols, n = 240, 260, 9000
+    rng = np.random.default_rng(12)
+    upd = np.abs(rng.normal(0.8, 0.6, (rows, cols)))
+    th = np.deg2rad(dirn)
+    rr = np.arange(rows)[:, None]; cc = np.arange(cols)[None, :]
+    along = rr * np.cos(th) + cc * np.sin(th)
+    pot = 1000. * (1 - (along - along.min()) / (along.max() - along.min()))
+    for _ in range(30):
+        r0, c0 = rng.integers(20, rows - 20), rng.integers(20, cols - 20)
+        pot = pot - 300. * np.exp(-((rr - r0) ** 2 + (cc - c0) ** 2) / (2. * 8. * 8.))
+    pot = pot.astype(np.float32)
+    starts = np.stack([rng.integers(0, rows, n), rng.integers(0, cols, n)], 1)
+    ref = c_oracle.simulate_tracks(dirn, starts, (rows, cols), 1, 1., upd, pot, seed=33, want_traj=False)
+    assert int((ref['lengths'] > 4 * (rows + cols)).sum()) > n // 10, 'the case is meant to wander'
+    for kw in (dict(ring=True), dict(ring=False)):
+        res = movmodel.simulate_tracks(dirn, starts, (rows, cols), 1, 1., upd, pot, seed=33, use_table=True, **kw)
+        lens, ends, hist = _no_traj_result(res)
+        assert np.array_equal(lens, ref['lengths']), kw
+        assert np.array_equal(hist, ref['hist']), kw
+        assert res.stats['window_launches'] > 0 and res.stats['tile_launches'] > 0, res.stats
