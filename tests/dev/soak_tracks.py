@@ -13,15 +13,26 @@ while time.time() - t0 < budget:
     seed = int(master.integers(0, 2**31))
     rng = np.random.default_rng(seed)
     rows, cols = int(rng.integers(5, 400)), int(rng.integers(5, 500))
+    if rng.random() < 0.15:                                   # more than one tile column (1024 cells)
+        rows, cols = int(rng.integers(5, 200)), int(rng.integers(1025, 2600))
     n = int(rng.choice([1, 7, 64, 65, 300, 2000, 9000, 20000]))
     dirn = float(rng.choice([0., 45., 90., 135., 180., 225., 270., 315., rng.uniform(0, 360)]))
-    kind = rng.choice(['rough', 'smooth', 'flat', 'speckle', 'nan'])
+    kind = rng.choice(['rough', 'smooth', 'flat', 'speckle', 'nan', 'wells'])
+    if kind == 'wells' and rows * cols > 40000:               # wandering tracks run to rows / 2 * cols / 2 moves
+        kind = 'rough'
     upd = np.abs(rng.normal(0.8, 0.6, (rows, cols)))
     if kind in ('speckle', 'nan'):
         upd[rng.random((rows, cols)) < 0.5] = 0.0
     ramp = 1000. * (1 - np.arange(rows)[:, None] / max(rows - 1., 1.))
     if kind == 'flat':
         pot = np.full((rows, cols), 7.0, dtype=np.float32)
+    elif kind == 'wells':                                     # tracks circle in the wells: window -> tile buckets
+        rr, cc = np.arange(rows)[:, None], np.arange(cols)[None, :]
+        pot = ramp + 0. * cc
+        for _ in range(int(rng.integers(1, 12))):
+            r0, c0 = rng.integers(0, rows), rng.integers(0, cols)
+            pot = pot - rng.uniform(100., 900.) * np.exp(-((rr - r0) ** 2 + (cc - c0) ** 2) / (2. * rng.uniform(3., 12.) ** 2))
+        pot = pot.astype(np.float32)
     elif kind == 'smooth':
         pot = (ramp + 0 * upd).astype(np.float32)
     else:
