@@ -1868,7 +1868,9 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
     const double off_axis = std::fabs(geom.sin_t) < std::fabs(geom.cos_t) ? std::fabs(geom.sin_t) : std::fabs(geom.cos_t);
     const uint32_t ntc = static_cast<uint32_t>((p->cols + kTileCols - 1) / kTileCols);
     const uint32_t ntiles = ntc * static_cast<uint32_t>((p->rows + kTileRows - 1) / kTileRows);
+    // (bucket offsets are 32-bit: a launch must make fewer than 2^32 visits)
     const bool tiles_ok = hist != nullptr && coherent && S <= kVisitSteps && ntracks >= 8192 && ntiles <= kTilesMax &&
+                          static_cast<unsigned long long>(ws.cap) * kXcd * static_cast<unsigned long long>(S) < (1ull << 32) &&
                           (p->flags & SSRS_TRACKS_NO_BINNING) == 0 && std::getenv("SSRS_TRACKS_NO_TILES") == nullptr;
     const bool force_tiles = tiles_ok && std::getenv("SSRS_TRACKS_FORCE_TILES") != nullptr;   // A/B switch
     bool tiles_on = tiles_ok && (off_axis > 0.17 || force_tiles);   // more than ~10 degrees off a raster axis
