@@ -20,6 +20,9 @@ for dirn in ([float(v) for v in sys.argv[1:]] or (0., 90., 45., 135., 30., 250.)
         r = t if dirn == 0. else rows - 1 - t; c = s * cols
     elif dirn in (90., 270.):
         c = t if dirn == 90. else cols - 1 - t; r = s * rows
+    elif os.environ.get('PROBE_SOUTH_BAND'):
+        # the Simulator's default start band (along the south edge) whatever the heading
+        r = t if np.cos(th) > 0 else rows - 1 - t; c = s * cols
     else:
         # oblique: start bands along the two upstream edges
         up_r = t if np.cos(th) > 0 else rows - 1 - t
