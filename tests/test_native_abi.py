@@ -64,3 +64,32 @@ def test_product_fails_loudly_without_gpu():
     from ssrs_amd import layers
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         layers.compute_slope_degrees(np.zeros((8, 8)), 10.)
+
+
+def test_ctypes_structs_match_the_header(tmp_path):
+    """The header's structs, compiled as plain C (gcc), have the size and field offsets of
+    their ctypes mirrors in ssrs_amd/_native.py."""
+    import ctypes, shutil, subprocess
+    from ssrs_amd import _native as nat
+    if shutil.which('gcc') is None:
+        pytest.skip('no gcc')
+    structs = {'SsrsTrackParams': nat.SsrsTrackParams, 'SsrsTrackStats': nat.SsrsTrackStats,
+               'SsrsSolveStats': nat.SsrsSolveStats}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "ssrs_hip.h"', 'int main(void) {']
+    for name, cls in structs.items():
+        lines.append(f'  printf("{name} %zu", sizeof({name}));')
+        for field, _ in cls._fields_:
+            lines.append(f'  printf(" %zu", offsetof({name}, {field}));')
+        lines.append('  printf("\\n");')
+    lines += ['  return 0;', '}']
+    src = tmp_path / 'abi.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'abi'
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include')
+    subprocess.run(['gcc', '-std=c99', '-Wall', '-Werror', '-I', inc, str(src), '-o', str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    for line in out:
+        name, size, *offsets = line.split()
+        cls = structs[name]
+        assert int(size) == ctypes.sizeof(cls), name
+        assert [int(o) for o in offsets] == [getattr(cls, f).offset for f, _ in cls._fields_], name
