@@ -1343,7 +1343,8 @@ __global__ __launch_bounds__(kBlock) void k_fold_copies(const uint32_t *__restri
     }
 }
 
-// K3 for oblique headings.  There a front diffuses along BOTH raster axes (heading 45 deg:
+// K3 for oblique headings and for batches that wander.  An oblique front diffuses along
+// BOTH raster axes (heading 45 deg:
 // the moves N, NE, E advance 1, 1, 0 rows): a step's visits span hundreds of rows, no
 // per-step row window holds them, and per-visit atomics run at the memory side's ~2e10/s
 // (27 ms per 100k tracks at C2 against 5 ms for axis-aligned headings).  But over one
@@ -1352,8 +1353,10 @@ __global__ __launch_bounds__(kBlock) void k_fold_copies(const uint32_t *__restri
 //   k_tile_sort<false>  counts visits per tile        (one read of the visit buffer)
 //   k_tile_scan         bucket starts
 //   k_tile_sort<true>   copies visits into buckets    (one read, one write)
-//   k_bin_bucket        one block per non-empty tile: LDS counters, row-wise flush
-// 0.8 GB of traffic per launch instead of 5e7 memory-side atomics.  The order inside a
+//   k_bin_bucket        one block per 65 536 visits of a tile: LDS counters, row-wise flush
+// 0.8 GB of traffic per launch instead of 5e7 memory-side atomics.  Tracks that circle in
+// pockets of a solved potential field (no front at all) concentrate their visits even
+// more: such batches move here from the row window as well (19 -> 27 G steps/s).  The order inside a
 // bucket is arbitrary; a histogram does not care.  A counter that reaches 0x8000 is
 // emptied by the one thread that saw it (LDS atomics return the old value; at most
 // 1023 x 16 other increments can land in between, so 16 bits never overflow).
