@@ -11,6 +11,7 @@ struct AmgLevel {
     int n = 0, nnz = 0, nc = 0;
     int *rowptr = nullptr, *col = nullptr;
     double *val = nullptr, *dinv = nullptr;
+    float *val32 = nullptr;    // the same entries rounded to f32 for the cycle's sweeps (levels >= 1)
     int *agg = nullptr;        // fine node -> coarse node (-1: isolated row), NULL on the last level
     int *memptr = nullptr;     // coarse node I -> its fine nodes memidx[memptr[I] .. memptr[I+1])
     int *memidx = nullptr;

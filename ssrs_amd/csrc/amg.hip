@@ -345,8 +345,9 @@ __global__ __launch_bounds__(kBlock) void k_jacobi_first(const double *__restric
 // consecutive entries, and the partial sums meet in a fixed shuffle tree
 // (reproducible).  Level 1 at 5000 x 6000: 1.15 ms -> see profiles/r01_notes.md.
 constexpr int kRowLanes = 4;
+template <class V>
 __device__ __forceinline__ double row_dot4(const int *__restrict__ rowptr, const int *__restrict__ col,
-                                           const double *__restrict__ val, const double *__restrict__ x,
+                                           const V *__restrict__ val, const double *__restrict__ x,
                                            int row, int sub)
 {
     double ax = 0.0;
@@ -357,9 +358,10 @@ __device__ __forceinline__ double row_dot4(const int *__restrict__ rowptr, const
     return ax;
 }
 
+template <class V>
 __global__ __launch_bounds__(kBlock) void k_jacobi4(const int *__restrict__ rowptr,
                                                    const int *__restrict__ col,
-                                                   const double *__restrict__ val,
+                                                   const V *__restrict__ val,
                                                    const double *__restrict__ dinv,
                                                    const double *__restrict__ b,
                                                    const double *__restrict__ x, int n,
@@ -376,9 +378,10 @@ __global__ __launch_bounds__(kBlock) void k_jacobi4(const int *__restrict__ rowp
     }
 }
 
+template <class V>
 __global__ __launch_bounds__(kBlock) void k_residual4(const int *__restrict__ rowptr,
                                                      const int *__restrict__ col,
-                                                     const double *__restrict__ val,
+                                                     const V *__restrict__ val,
                                                      const double *__restrict__ b,
                                                      const double *__restrict__ x, int n,
                                                      double *__restrict__ r)
@@ -393,9 +396,10 @@ __global__ __launch_bounds__(kBlock) void k_residual4(const int *__restrict__ ro
     }
 }
 
+template <class V>
 __global__ __launch_bounds__(kBlock) void k_jacobi(const int *__restrict__ rowptr,
                                                   const int *__restrict__ col,
-                                                  const double *__restrict__ val,
+                                                  const V *__restrict__ val,
                                                   const double *__restrict__ dinv,
                                                   const double *__restrict__ b,
                                                   const double *__restrict__ x, int n,
@@ -408,9 +412,10 @@ __global__ __launch_bounds__(kBlock) void k_jacobi(const int *__restrict__ rowpt
     }
 }
 
+template <class V>
 __global__ __launch_bounds__(kBlock) void k_residual(const int *__restrict__ rowptr,
                                                     const int *__restrict__ col,
-                                                    const double *__restrict__ val,
+                                                    const V *__restrict__ val,
                                                     const double *__restrict__ b,
                                                     const double *__restrict__ x, int n,
                                                     double *__restrict__ r)
@@ -422,6 +427,18 @@ __global__ __launch_bounds__(kBlock) void k_residual(const int *__restrict__ row
     }
 }
 
+// The cycle's sweeps on the CSR levels read f32 copies of the entries (8 instead of 12 B
+// per non-zero; these kernels move bytes).  Rounded so that the copy stays a symmetric
+// M-matrix: off-diagonals (<= 0) toward zero, the diagonal upward, hence still diagonally
+// dominant, and a_ij = a_ji round alike.  Set-up (strength, Galerkin, dense inverse) keeps f64.
+__global__ __launch_bounds__(kBlock) void k_val32(const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                 const double *__restrict__ val, int n, float *__restrict__ out)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+        for (int p = rowptr[i]; p < rowptr[i + 1]; ++p)
+            out[p] = col[p] == i ? __double2float_ru(val[p]) : __double2float_rz(val[p]);
+}
+
 // ---- level 0 matrix-free ----------------------------------------------------
 // The finest level is a 9-point stencil on the raster: applying it from the
 // reciprocal conductances (8 B per cell, neighbours through L2) moves ~40 B per cell
@@ -430,42 +447,69 @@ __global__ __launch_bounds__(kBlock) void k_residual(const int *__restrict__ row
 // the five level-0 sweeps were two thirds of a V-cycle.  The CSR copy of level 0 is
 // still built: the aggregation and the Galerkin product read it.
 struct L0Stencil {
-    const double *rinv;       // 1 / cond, 0 where cond == 0 (then every link is 1e-8)
+    const double *rinv;       // 1 / cond, 0 where cond == 0 (then every link is 1e-8); the sign
+                              // bit marks Dirichlet cells (saves nine byte loads per cell)
     const uint8_t *fixed;
     int rows, cols;
 };
 
-__global__ __launch_bounds__(kBlock) void k_l0_rinv(const double *__restrict__ cond, size_t n,
+__global__ __launch_bounds__(kBlock) void k_l0_rinv(const double *__restrict__ cond,
+                                                   const uint8_t *__restrict__ fixed, size_t n,
                                                    double *__restrict__ rinv)
 {
     for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
          i += static_cast<size_t>(gridDim.x) * kBlock) {
         const double c = cond[i];
-        rinv[i] = c != 0.0 ? 1.0 / c : 0.0;
+        const double v = c != 0.0 ? fabs(1.0 / c) : 0.0;      // conductances are >= 0
+        rinv[i] = fixed[i] ? -v : v;
     }
 }
 
-// (A x)_i of the level-0 operator (same weights as k_l0_fill, same bits)
-__device__ __forceinline__ double l0_apply(const L0Stencil &a, const double *__restrict__ x, size_t i)
+// (A x)_i of the level-0 operator.  The weights are those of k_l0_fill up to rounding
+// (diagonal links are multiplied by 1/sqrt(2) instead of divided by sqrt(2)): this operator
+// only preconditions, what it must be is symmetric (w_ij is a function of ri + rj) and
+// diagonally dominant (diag = the sum of the same w_ij), which it is by construction.
+constexpr double kInvFacDiag = 1.0 / 1.41421353816986083984375;
+
+// One wave = one row segment of 62 cells plus a halo lane on either side: every lane loads
+// its own column of the three rows (six loads for x and rinv), the east / west neighbours
+// arrive by lane shuffles.  The kernels were bound by the number of load instructions (21
+// per cell with a thread-per-cell stencil: 0.66 ms per sweep at 5000 x 6000), not by bytes.
+constexpr int kL0Cols = 62;                                   // cells per wave
+__device__ __forceinline__ double l0_apply_wave(const L0Stencil &a, const double *__restrict__ x,
+                                                int r, int c, bool &centre, size_t &i)
 {
-    if (a.fixed[i]) return x[i];
-    const int r = static_cast<int>(i / a.cols), c = static_cast<int>(i % a.cols);
-    const double ri = a.rinv[i];
+    const int lane = threadIdx.x & 63;
+    const bool col_ok = c >= 0 && c < a.cols;
+    double xv[3], sv[3];                                      // rows r-1, r, r+1 of this lane's column
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int rr = r + d - 1;
+        const bool ok = col_ok && rr >= 0 && rr < a.rows;
+        const size_t j = static_cast<size_t>(ok ? rr : r) * a.cols + (col_ok ? c : 0);
+        xv[d] = ok ? x[j] : 0.0;
+        sv[d] = ok ? a.rinv[j] : __builtin_inf();             // +inf: outside the raster, no link
+    }
+    i = static_cast<size_t>(r) * a.cols + (col_ok ? c : 0);
+    centre = col_ok && lane >= 1 && lane <= kL0Cols;
+    const double si = sv[1], ri = si;
     double diag = 0.0, off = 0.0;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
+    for (int k = 0; k < 9; ++k) {                             // same order as before: rows south to north
         if (k == 4) continue;
-        const int dr = k / 3 - 1, dc = k % 3 - 1;
-        const int rr = r + dr, cc = c + dc;
-        if (rr < 0 || rr >= a.rows || cc < 0 || cc >= a.cols) continue;
-        const size_t j = static_cast<size_t>(rr) * a.cols + cc;
-        const double rj = a.rinv[j];
+        const int d = k / 3, dc = k % 3 - 1;
+        double sj = sv[d], xj = xv[d];
+        if (dc < 0) { sj = __shfl_up(sj, 1); xj = __shfl_up(xj, 1); }
+        if (dc > 0) { sj = __shfl_down(sj, 1); xj = __shfl_down(xj, 1); }
+        const double rj = fabs(sj);
         double w = (ri != 0.0 && rj != 0.0) ? 2.0 / (ri + rj) : 1e-08;
-        if (dr && dc) w = w / 1.41421353816986083984375;
+        if (rj == __builtin_inf()) w = 0.0;
+        if (d != 1 && dc != 0) w = w * kInvFacDiag;
         diag += w;
-        if (!a.fixed[j]) off += w * x[j];
+        if (!signbit(sj)) off += w * xj;
     }
-    return diag * x[i] - off;
+    if (signbit(si)) return xv[1];                            // Dirichlet cell: identity row
+    return diag * xv[1] - off;
 }
 
 __global__ __launch_bounds__(kBlock) void k_l0_jacobi(L0Stencil a, const double *__restrict__ dinv,
@@ -473,20 +517,24 @@ __global__ __launch_bounds__(kBlock) void k_l0_jacobi(L0Stencil a, const double 
                                                      const double *__restrict__ x,
                                                      double *__restrict__ xn)
 {
-    const size_t n = static_cast<size_t>(a.rows) * a.cols;
-    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
-         i += static_cast<size_t>(gridDim.x) * kBlock)
-        xn[i] = x[i] + kOmega * dinv[i] * (b[i] - l0_apply(a, x, i));
+    const int c = (static_cast<int>(blockIdx.x) * (kBlock / 64) + static_cast<int>(threadIdx.x >> 6)) * kL0Cols +
+                  static_cast<int>(threadIdx.x & 63) - 1;
+    bool centre;
+    size_t i;
+    const double ax = l0_apply_wave(a, x, static_cast<int>(blockIdx.y), c, centre, i);
+    if (centre) xn[i] = x[i] + kOmega * dinv[i] * (b[i] - ax);
 }
 
 __global__ __launch_bounds__(kBlock) void k_l0_residual(L0Stencil a, const double *__restrict__ b,
                                                        const double *__restrict__ x,
                                                        double *__restrict__ r)
 {
-    const size_t n = static_cast<size_t>(a.rows) * a.cols;
-    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
-         i += static_cast<size_t>(gridDim.x) * kBlock)
-        r[i] = b[i] - l0_apply(a, x, i);
+    const int c = (static_cast<int>(blockIdx.x) * (kBlock / 64) + static_cast<int>(threadIdx.x >> 6)) * kL0Cols +
+                  static_cast<int>(threadIdx.x & 63) - 1;
+    bool centre;
+    size_t i;
+    const double ax = l0_apply_wave(a, x, static_cast<int>(blockIdx.y), c, centre, i);
+    if (centre) r[i] = b[i] - ax;
 }
 
 __global__ __launch_bounds__(kBlock) void k_restrict(const int *__restrict__ memptr,
@@ -745,7 +793,7 @@ int amg_setup(AmgHierarchy &h, const double *cond, const uint8_t *fixed, int row
     {
         double *rinv;
         AMG_TAKE(rinv, double, n0);
-        hipLaunchKernelGGL(k_l0_rinv, dim3(grid_for(n0)), dim3(kBlock), 0, st, cond, static_cast<size_t>(n0), rinv);
+        hipLaunchKernelGGL(k_l0_rinv, dim3(grid_for(n0)), dim3(kBlock), 0, st, cond, fixed, static_cast<size_t>(n0), rinv);
         h.l0_rinv = rinv;
         h.l0_fixed = fixed;
         h.l0_rows = rows;
@@ -861,6 +909,9 @@ int amg_setup(AmgHierarchy &h, const double *cond, const uint8_t *fixed, int row
         SSRS_HIP_CHECK(hipStreamSynchronize(st));
         if (last_key == ~0ull) --nuniq;            // the parked bucket
 
+        if (std::getenv("SSRS_PROGRESS"))
+            fprintf(stderr, "[amg] level %d: %d rows, %d nnz -> %d rows, %d nnz%s\n", lev, n, L.nnz, nc, nuniq,
+                    permissive ? " (permissive)" : "");
         AmgLevel C{};
         C.n = nc;
         C.nnz = nuniq;
@@ -874,6 +925,22 @@ int amg_setup(AmgHierarchy &h, const double *cond, const uint8_t *fixed, int row
         L = C;
     }
     if (h.levels.empty()) return set_error(SSRS_ERR_INVALID, "amg: empty hierarchy");
+
+    // ---- f32 copies of the coarse matrices for the cycle, in the (now free) sort scratch
+    if (!std::getenv("SSRS_AMG_F64")) {
+        float *pool = reinterpret_cast<float *>(vals_b);
+        const size_t room = 2 * static_cast<size_t>(h.levels[0].nnz);
+        size_t used = 0;
+        for (size_t lev = 1; lev < h.levels.size(); ++lev) {
+            AmgLevel &Lv = h.levels[lev];
+            const size_t need = (static_cast<size_t>(Lv.nnz) + 63) / 64 * 64;
+            if (used + need > room) break;                   // (never seen: coarse levels shrink 2.3x each)
+            Lv.val32 = pool + used;
+            used += need;
+            hipLaunchKernelGGL(k_val32, dim3(grid_for(Lv.n)), dim3(kBlock), 0, st, Lv.rowptr, Lv.col, Lv.val, Lv.n, Lv.val32);
+        }
+        SSRS_HIP_CHECK(hipGetLastError());
+    }
 
     // ---- dense inverse of the coarsest level when it is small enough
     AmgLevel &B = h.levels.back();
@@ -901,18 +968,29 @@ static void solve_level(AmgHierarchy &h, size_t lev, hipStream_t st);
 
 constexpr int kVectorRows = 1 << 17;     // levels at least this large use four lanes per row
 
+// level-0 stencil kernels: blockIdx.y = row, a block = 4 waves x 62 cells of it
+static dim3 l0_grid(const AmgHierarchy &h)
+{
+    const int per_block = (kBlock / 64) * kL0Cols;
+    return dim3(static_cast<unsigned>((h.l0_cols + per_block - 1) / per_block), static_cast<unsigned>(h.l0_rows));
+}
+
 static void launch_jacobi(AmgHierarchy &h, size_t lev, const double *x, double *xn, hipStream_t st)
 {
     AmgLevel &L = h.levels[lev];
     if (lev == 0 && h.l0_rinv && !getenv("SSRS_AMG_L0_CSR")) {
         const L0Stencil a{h.l0_rinv, h.l0_fixed, h.l0_rows, h.l0_cols};
-        hipLaunchKernelGGL(k_l0_jacobi, dim3(grid_for(L.n)), dim3(kBlock), 0, st, a, L.dinv, L.b, x, xn);
+        hipLaunchKernelGGL(k_l0_jacobi, l0_grid(h), dim3(kBlock), 0, st, a, L.dinv, L.b, x, xn);
     } else {
-        if (L.n >= kVectorRows)
-            hipLaunchKernelGGL(k_jacobi4, dim3(grid_for(static_cast<size_t>(L.n) * kRowLanes)), dim3(kBlock), 0, st,
-                               L.rowptr, L.col, L.val, L.dinv, L.b, x, L.n, xn);
+        const dim3 g4(grid_for(static_cast<size_t>(L.n) * kRowLanes)), g1(grid_for(L.n));
+        if (L.n >= kVectorRows && L.val32)
+            hipLaunchKernelGGL(k_jacobi4<float>, g4, dim3(kBlock), 0, st, L.rowptr, L.col, L.val32, L.dinv, L.b, x, L.n, xn);
+        else if (L.n >= kVectorRows)
+            hipLaunchKernelGGL(k_jacobi4<double>, g4, dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.dinv, L.b, x, L.n, xn);
+        else if (L.val32)
+            hipLaunchKernelGGL(k_jacobi<float>, g1, dim3(kBlock), 0, st, L.rowptr, L.col, L.val32, L.dinv, L.b, x, L.n, xn);
         else
-            hipLaunchKernelGGL(k_jacobi, dim3(grid_for(L.n)), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.dinv, L.b, x, L.n, xn);
+            hipLaunchKernelGGL(k_jacobi<double>, g1, dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.dinv, L.b, x, L.n, xn);
     }
 }
 
@@ -921,13 +999,17 @@ static void launch_residual(AmgHierarchy &h, size_t lev, hipStream_t st)
     AmgLevel &L = h.levels[lev];
     if (lev == 0 && h.l0_rinv && !getenv("SSRS_AMG_L0_CSR")) {
         const L0Stencil a{h.l0_rinv, h.l0_fixed, h.l0_rows, h.l0_cols};
-        hipLaunchKernelGGL(k_l0_residual, dim3(grid_for(L.n)), dim3(kBlock), 0, st, a, L.b, L.x, L.r);
+        hipLaunchKernelGGL(k_l0_residual, l0_grid(h), dim3(kBlock), 0, st, a, L.b, L.x, L.r);
     } else {
-        if (L.n >= kVectorRows)
-            hipLaunchKernelGGL(k_residual4, dim3(grid_for(static_cast<size_t>(L.n) * kRowLanes)), dim3(kBlock), 0, st,
-                               L.rowptr, L.col, L.val, L.b, L.x, L.n, L.r);
+        const dim3 g4(grid_for(static_cast<size_t>(L.n) * kRowLanes)), g1(grid_for(L.n));
+        if (L.n >= kVectorRows && L.val32)
+            hipLaunchKernelGGL(k_residual4<float>, g4, dim3(kBlock), 0, st, L.rowptr, L.col, L.val32, L.b, L.x, L.n, L.r);
+        else if (L.n >= kVectorRows)
+            hipLaunchKernelGGL(k_residual4<double>, g4, dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.b, L.x, L.n, L.r);
+        else if (L.val32)
+            hipLaunchKernelGGL(k_residual<float>, g1, dim3(kBlock), 0, st, L.rowptr, L.col, L.val32, L.b, L.x, L.n, L.r);
         else
-            hipLaunchKernelGGL(k_residual, dim3(grid_for(L.n)), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.b, L.x, L.n, L.r);
+            hipLaunchKernelGGL(k_residual<double>, g1, dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.b, L.x, L.n, L.r);
     }
 }
 

@@ -38,12 +38,16 @@ __device__ __forceinline__ double pair_conductance(double a, double b)
 // If DOTS: accumulates block partials of (w, y) and (y, y) [w may be NULL -> (x, y)].
 struct StencilArgs {
     const double *cond;
+    const double *rinv;       // +-1 / cond (0 where cond == 0; sign bit = Dirichlet cell, amg.hip)
+                              // when the AMG set it up, else NULL: 2 / (1/a + 1/b) then
+                              // costs one division per link, same bits
     const uint8_t *fixed;     // 1 = Dirichlet
     int rows, cols;
     int unnormalised;         // 1: rows of D - C (pairs with the AMG of D - C);
                               // 0: rows of I - G (= Jacobi-scaled, plain Krylov)
     int quirk;                // 1: the reference's east-edge weights (exact operator);
                               // 0: natural weights (symmetric operator, PCG phase)
+    TileWalk walk;            // tile order of the stencil kernels (common.h)
 };
 
 __device__ __forceinline__ double apply_row(const StencilArgs &a, const double *__restrict__ x,
@@ -51,7 +55,8 @@ __device__ __forceinline__ double apply_row(const StencilArgs &a, const double *
 {
     const int R = a.rows, C = a.cols;
     const size_t i = static_cast<size_t>(r) * C + c;
-    const double ci = a.cond[i];
+    const bool pre = a.rinv != nullptr;
+    const double ci = pre ? fabs(a.rinv[i]) : a.cond[i];
     double wsum = 0.0, acc = 0.0;
     const bool east_quirk = a.quirk && (c == C - 1) && r > 0 && r < R - 1;
     // neighbour order is irrelevant for the mathematics; the sum order below is
@@ -65,7 +70,13 @@ __device__ __forceinline__ double apply_row(const StencilArgs &a, const double *
         bool diag = (dr != 0 && dc != 0);
         if (east_quirk && dr == -1) diag = !diag;     // S <-> SW weights swapped
         const size_t j = static_cast<size_t>(rr) * C + cc;
-        double w = pair_conductance(ci, a.cond[j]);
+        double w;
+        if (pre) {
+            const double rj = fabs(a.rinv[j]);
+            w = (ci != 0.0 && rj != 0.0) ? 2.0 / (ci + rj) : 1e-08;
+        } else {
+            w = pair_conductance(ci, a.cond[j]);
+        }
         if (diag) w = w / SSRS_FAC_DIAG;
         wsum += w;
         acc += w * x[j];
@@ -73,7 +84,7 @@ __device__ __forceinline__ double apply_row(const StencilArgs &a, const double *
     return a.unnormalised ? wsum * x[i] - acc : x[i] - acc / wsum;
 }
 
-constexpr int kRedBlocks = 1024;
+constexpr int kRedBlocks = 4096;
 
 __device__ __forceinline__ double block_sum(double v, double *lds)
 {
@@ -101,15 +112,13 @@ __global__ __launch_bounds__(kBlock) void k_apply_dot1(StencilArgs a, const doub
                                                       const double *__restrict__ rhat, Scalars *s)
 {
     __shared__ double lds[kBlock / 64];
-    const size_t n = static_cast<size_t>(a.rows) * a.cols;
     double d = 0.0;
-    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
-         i += static_cast<size_t>(gridDim.x) * kBlock) {
+    for_each_cell(a.walk, [&](size_t i, int r, int c) {
         double y = 0.0;
-        if (!a.fixed[i]) y = apply_row(a, p, static_cast<int>(i / a.cols), static_cast<int>(i % a.cols));
+        if (!a.fixed[i]) y = apply_row(a, p, r, c);
         v[i] = y;
         d += rhat[i] * y;
-    }
+    });
     d = block_sum(d, lds);
     if (threadIdx.x == 0) s->part[0][blockIdx.x] = d;
 }
@@ -131,16 +140,14 @@ __global__ __launch_bounds__(kBlock) void k_apply_dot2(StencilArgs a, const doub
                                                       const double *__restrict__ sv, Scalars *s)
 {
     __shared__ double lds[kBlock / 64];
-    const size_t n = static_cast<size_t>(a.rows) * a.cols;
     double d1 = 0.0, d2 = 0.0;
-    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
-         i += static_cast<size_t>(gridDim.x) * kBlock) {
+    for_each_cell(a.walk, [&](size_t i, int r, int c) {
         double y = 0.0;
-        if (!a.fixed[i]) y = apply_row(a, in, static_cast<int>(i / a.cols), static_cast<int>(i % a.cols));
+        if (!a.fixed[i]) y = apply_row(a, in, r, c);
         t[i] = y;
         d1 += y * sv[i];
         d2 += y * y;
-    }
+    });
     d1 = block_sum(d1, lds);
     d2 = block_sum(d2, lds);
     if (threadIdx.x == 0) { s->part[1][blockIdx.x] = d1; s->part[2][blockIdx.x] = d2; }
@@ -251,22 +258,151 @@ __global__ __launch_bounds__(kBlock) void k_cg_p(double *__restrict__ p,
         p[i] = z[i] + beta * p[i];
 }
 
+// The same row for one wave = 62 cells of a raster row plus one halo lane on either side
+// (needs a.rinv): six loads per lane, the east / west neighbours by lane shuffles.  The
+// thread-per-cell form is bound by its 17 load instructions per cell, not by bytes
+// (0.79 -> 0.5 ms per application at 5000 x 6000).  Same operation order, same bits.
+constexpr int kWaveCols = 62;
+__device__ __forceinline__ double apply_row_wave(const StencilArgs &a, const double *__restrict__ x, int r,
+                                                 int c, bool &centre, bool &fixed, size_t &i, double &xi)
+{
+    const int R = a.rows, C = a.cols, lane = threadIdx.x & 63;
+    const bool col_ok = c >= 0 && c < C;
+    double xv[3], sv[3];                                      // rows r-1, r, r+1 of this lane's column
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int rr = r + d - 1;
+        const bool ok = col_ok && rr >= 0 && rr < R;
+        const size_t j = static_cast<size_t>(ok ? rr : r) * C + (col_ok ? c : 0);
+        xv[d] = ok ? x[j] : 0.0;
+        sv[d] = ok ? a.rinv[j] : __builtin_inf();             // +inf: outside the raster, no link
+    }
+    i = static_cast<size_t>(r) * C + (col_ok ? c : 0);
+    centre = col_ok && lane >= 1 && lane <= kWaveCols;
+    fixed = signbit(sv[1]);
+    xi = xv[1];
+    const double ci = fabs(sv[1]);
+    double wsum = 0.0, acc = 0.0;
+    const bool east_quirk = a.quirk && (c == C - 1) && r > 0 && r < R - 1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {                             // W, NW, N, NE, E, SE, S, SW as in apply_row
+        const int dr = (k == 1 || k == 2 || k == 3) ? 1 : ((k == 5 || k == 6 || k == 7) ? -1 : 0);
+        const int dc = (k == 0 || k == 1 || k == 7) ? -1 : ((k == 3 || k == 4 || k == 5) ? 1 : 0);
+        double sj = sv[dr + 1], xj = xv[dr + 1];
+        if (dc < 0) { sj = __shfl_up(sj, 1); xj = __shfl_up(xj, 1); }
+        if (dc > 0) { sj = __shfl_down(sj, 1); xj = __shfl_down(xj, 1); }
+        const double rj = fabs(sj);
+        bool diag = (dr != 0 && dc != 0);
+        if (east_quirk && dr == -1) diag = !diag;             // S <-> SW weights swapped
+        double w = (ci != 0.0 && rj != 0.0) ? 2.0 / (ci + rj) : 1e-08;
+        if (diag) w = w / SSRS_FAC_DIAG;
+        if (rj == __builtin_inf()) w = 0.0;                   // (adds exact zeros: same sums as skipping)
+        wsum += w;
+        acc += w * xj;
+    }
+    return a.unnormalised ? wsum * xv[1] - acc : xv[1] - acc / wsum;
+}
+
+__global__ __launch_bounds__(kBlock) void k_cg_apply_wave(StencilArgs a, const double *__restrict__ p,
+                                                         double *__restrict__ q,
+                                                         const double *__restrict__ r, Scalars *s)
+{
+    __shared__ double lds[kBlock / 64];
+    const int per_block = (kBlock / 64) * kWaveCols;
+    const int segs = (a.cols + per_block - 1) / per_block;
+    const long long items = static_cast<long long>(a.rows) * segs;
+    double d0 = 0.0, d1 = 0.0;
+    for (long long it = blockIdx.x; it < items; it += gridDim.x) {
+        const int row = static_cast<int>(it / segs), seg = static_cast<int>(it - static_cast<long long>(row) * segs);
+        const int c = (seg * (kBlock / 64) + static_cast<int>(threadIdx.x >> 6)) * kWaveCols +
+                      static_cast<int>(threadIdx.x & 63) - 1;
+        bool centre, fixed;
+        size_t i;
+        double pi;
+        double y = apply_row_wave(a, p, row, c, centre, fixed, i, pi);
+        if (centre) {
+            if (fixed) y = 0.0;
+            q[i] = y;
+            d0 += pi * y;
+            d1 += pi * r[i];
+        }
+    }
+    d0 = block_sum(d0, lds);
+    d1 = block_sum(d1, lds);
+    if (threadIdx.x == 0) { s->part[0][blockIdx.x] = d0; s->part[1][blockIdx.x] = d1; }
+}
+
+// wave forms of k_apply_dot1 / k_apply_dot2 (BiCGStab polish on the exact operator)
+__global__ __launch_bounds__(kBlock) void k_apply_dot1_wave(StencilArgs a, const double *__restrict__ p,
+                                                           double *__restrict__ v,
+                                                           const double *__restrict__ rhat, Scalars *s)
+{
+    __shared__ double lds[kBlock / 64];
+    const int per_block = (kBlock / 64) * kWaveCols;
+    const int segs = (a.cols + per_block - 1) / per_block;
+    const long long items = static_cast<long long>(a.rows) * segs;
+    double d = 0.0;
+    for (long long it = blockIdx.x; it < items; it += gridDim.x) {
+        const int row = static_cast<int>(it / segs), seg = static_cast<int>(it - static_cast<long long>(row) * segs);
+        const int c = (seg * (kBlock / 64) + static_cast<int>(threadIdx.x >> 6)) * kWaveCols +
+                      static_cast<int>(threadIdx.x & 63) - 1;
+        bool centre, fixed;
+        size_t i;
+        double pi;
+        double y = apply_row_wave(a, p, row, c, centre, fixed, i, pi);
+        if (centre) {
+            if (fixed) y = 0.0;
+            v[i] = y;
+            d += rhat[i] * y;
+        }
+    }
+    d = block_sum(d, lds);
+    if (threadIdx.x == 0) s->part[0][blockIdx.x] = d;
+}
+
+__global__ __launch_bounds__(kBlock) void k_apply_dot2_wave(StencilArgs a, const double *__restrict__ in,
+                                                           double *__restrict__ t,
+                                                           const double *__restrict__ sv, Scalars *s)
+{
+    __shared__ double lds[kBlock / 64];
+    const int per_block = (kBlock / 64) * kWaveCols;
+    const int segs = (a.cols + per_block - 1) / per_block;
+    const long long items = static_cast<long long>(a.rows) * segs;
+    double d1 = 0.0, d2 = 0.0;
+    for (long long it = blockIdx.x; it < items; it += gridDim.x) {
+        const int row = static_cast<int>(it / segs), seg = static_cast<int>(it - static_cast<long long>(row) * segs);
+        const int c = (seg * (kBlock / 64) + static_cast<int>(threadIdx.x >> 6)) * kWaveCols +
+                      static_cast<int>(threadIdx.x & 63) - 1;
+        bool centre, fixed;
+        size_t i;
+        double xi;
+        double y = apply_row_wave(a, in, row, c, centre, fixed, i, xi);
+        if (centre) {
+            if (fixed) y = 0.0;
+            t[i] = y;
+            d1 += y * sv[i];
+            d2 += y * y;
+        }
+    }
+    d1 = block_sum(d1, lds);
+    d2 = block_sum(d2, lds);
+    if (threadIdx.x == 0) { s->part[1][blockIdx.x] = d1; s->part[2][blockIdx.x] = d2; }
+}
+
 // q = A p ; partials (p, q) and (p, r)
 __global__ __launch_bounds__(kBlock) void k_cg_apply(StencilArgs a, const double *__restrict__ p,
                                                     double *__restrict__ q,
                                                     const double *__restrict__ r, Scalars *s)
 {
     __shared__ double lds[kBlock / 64];
-    const size_t n = static_cast<size_t>(a.rows) * a.cols;
     double d0 = 0.0, d1 = 0.0;
-    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
-         i += static_cast<size_t>(gridDim.x) * kBlock) {
+    for_each_cell(a.walk, [&](size_t i, int rr, int cc) {
         double y = 0.0;
-        if (!a.fixed[i]) y = apply_row(a, p, static_cast<int>(i / a.cols), static_cast<int>(i % a.cols));
+        if (!a.fixed[i]) y = apply_row(a, p, rr, cc);
         q[i] = y;
         d0 += p[i] * y;
         d1 += p[i] * r[i];
-    }
+    });
     d0 = block_sum(d0, lds);
     d1 = block_sum(d1, lds);
     if (threadIdx.x == 0) { s->part[0][blockIdx.x] = d0; s->part[1][blockIdx.x] = d1; }
@@ -298,15 +434,13 @@ __global__ __launch_bounds__(kBlock) void k_setup(StencilArgs a, const double *_
                                                  Scalars *s)
 {
     __shared__ double lds[kBlock / 64];
-    const size_t n = static_cast<size_t>(a.rows) * a.cols;
     double d = 0.0;
-    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
-         i += static_cast<size_t>(gridDim.x) * kBlock) {
+    for_each_cell(a.walk, [&](size_t i, int rr, int cc) {
         double res = 0.0;
-        if (!a.fixed[i]) res = -apply_row(a, x, static_cast<int>(i / a.cols), static_cast<int>(i % a.cols));
+        if (!a.fixed[i]) res = -apply_row(a, x, rr, cc);
         r[i] = res; rhat[i] = res; p[i] = res; v[i] = 0.0;
         d += res * res;
-    }
+    });
     d = block_sum(d, lds);
     if (threadIdx.x == 0) s->part[4][blockIdx.x] = d;
 }
@@ -403,7 +537,8 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
         const int rc = amg_setup(amg, conductivity, fixed_mask, rows, cols, amg_base, amg_bytes, st);
         if (rc != SSRS_OK) return rc;
     }
-    StencilArgs a{conductivity, fixed_mask, rows, cols, use_amg ? 1 : 0, 1};
+    StencilArgs a{conductivity, use_amg ? amg.l0_rinv : nullptr, fixed_mask, rows, cols, use_amg ? 1 : 0, 1,
+                  make_tile_walk(rows, cols)};
     int nb = static_cast<int>((n + kBlock - 1) / kBlock);
     if (nb > kRedBlocks) nb = kRedBlocks;
     hipEvent_t e0, e1;
@@ -444,7 +579,10 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
                 hipLaunchKernelGGL(k_cg_dot_rz, dim3(nb), dim3(kBlock), 0, st, phat, v, n, sc);      // (z, q_prev)
                 hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, st, sc, FIN_CG_RHO, nb);
                 hipLaunchKernelGGL(k_cg_p, dim3(nb), dim3(kBlock), 0, st, p, phat, n, sc, cg_iterations == 0 ? 1 : 0);
-                hipLaunchKernelGGL(k_cg_apply, dim3(nb), dim3(kBlock), 0, st, as, p, v, r, sc);     // q = A p
+                if (as.rinv)                                                                     // q = A p
+                    hipLaunchKernelGGL(k_cg_apply_wave, dim3(nb), dim3(kBlock), 0, st, as, p, v, r, sc);
+                else
+                    hipLaunchKernelGGL(k_cg_apply, dim3(nb), dim3(kBlock), 0, st, as, p, v, r, sc);
                 hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, st, sc, FIN_CG_ALPHA, nb);
                 hipLaunchKernelGGL(k_cg_xr, dim3(nb), dim3(kBlock), 0, st, x, r, p, v, n, sc);
                 hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, st, sc, FIN_CG_RR, nb);
@@ -479,11 +617,13 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
             fresh = false;
             const double *ph = p, *sh = sv;
             if (use_amg) { amg_apply(amg, p, phat, st); ph = phat; }
-            hipLaunchKernelGGL(k_apply_dot1, dim3(nb), dim3(kBlock), 0, st, a, ph, v, rhat, sc);
+            if (a.rinv) hipLaunchKernelGGL(k_apply_dot1_wave, dim3(nb), dim3(kBlock), 0, st, a, ph, v, rhat, sc);
+            else hipLaunchKernelGGL(k_apply_dot1, dim3(nb), dim3(kBlock), 0, st, a, ph, v, rhat, sc);
             hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, st, sc, FIN_ALPHA, nb);
             hipLaunchKernelGGL(k_form_s, dim3(nb), dim3(kBlock), 0, st, r, v, sv, n, sc);
             if (use_amg) { amg_apply(amg, sv, shat, st); sh = shat; }
-            hipLaunchKernelGGL(k_apply_dot2, dim3(nb), dim3(kBlock), 0, st, a, sh, t, sv, sc);
+            if (a.rinv) hipLaunchKernelGGL(k_apply_dot2_wave, dim3(nb), dim3(kBlock), 0, st, a, sh, t, sv, sc);
+            else hipLaunchKernelGGL(k_apply_dot2, dim3(nb), dim3(kBlock), 0, st, a, sh, t, sv, sc);
             hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, st, sc, FIN_OMEGA, nb);
             hipLaunchKernelGGL(k_update_xr, dim3(nb), dim3(kBlock), 0, st, x, r, ph, sh, sv, t, rhat, n, sc);
             hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, st, sc, FIN_RHO, nb);

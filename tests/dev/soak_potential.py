@@ -29,37 +29,38 @@ def assemble(conductivity, move_dirn):
     return (ss.eye(inodes.size).tocsc() - gi[:, inodes]).tocsc(), gi[:, bnodes].dot(benergy), inodes, bnodes, benergy
 
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.
-t0 = time.time(); n_case = 0; worst = 0.0; its = []; worst_ratio = 0.0; worst_res = 0.0
-master = np.random.default_rng(4242)
-while time.time() - t0 < budget:
-    seed = int(master.integers(0, 2**31)); rng = np.random.default_rng(seed)
-    rows, cols = int(rng.integers(6, 90)), int(rng.integers(6, 110))
-    dirn = float(rng.choice([0., 45., 90., 135., 180., 225., 270., 315., -45., rng.uniform(0, 360)]))
-    cond = np.abs(rng.normal(0.8, 0.6, (rows, cols))) * 10.0 ** rng.uniform(-3, 1)
-    dead = rng.choice([0.0, 0.2, 0.5, 0.7])
-    cond[rng.random((rows, cols)) < dead] = 0.0
-    if rng.random() < 0.3:                                   # contiguous dead block
-        r0, c0 = int(rng.integers(0, rows - 3)), int(rng.integers(0, cols - 3))
-        cond[r0:r0 + rows // 3, c0:c0 + cols // 3] = 0.0
-    a_mat, b_vec, inodes, bnodes, benergy = assemble(cond, dirn)
-    x_ref = ssl.spsolve(a_mat, b_vec)
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        pot, st = solve_potential(cond, dirn, rel_tol=float(os.environ.get('SOAK_TOL', '1e-14')), max_iterations=3000, return_stats=True)
-    x_gpu = np.asarray(pot, dtype=np.float64).T.reshape(-1)[inodes]          # node id = col * nrow + row
-    bn = np.linalg.norm(b_vec)
-    res_ref = np.linalg.norm(a_mat @ x_ref - b_vec) / bn
-    res_gpu = np.linalg.norm(a_mat @ x_gpu - b_vec) / bn                      # f32-rounded field!
-    err = float(np.abs(x_gpu - x_ref).max())
-    worst = max(worst, err); its.append(st['iterations']); worst_ratio = max(worst_ratio, res_gpu / max(res_ref, 1e-300))
-    worst_res = max(worst_res, res_gpu)
-    # the systems have condition numbers up to ~1e10, so the two answers may differ by more than
-    # an f32 ulp; what must hold is that ours solves the reference's system as well as an
-    # f32-rounded field can (residual of f32 rounding alone is ~1e-7)
-    if res_gpu > 1e-5 or err > float(os.environ.get('SOAK_ERR', '5e-3')):
-        print('MISMATCH', dict(seed=seed, rows=rows, cols=cols, dirn=dirn, dead=float(dead)), st, err, res_ref, res_gpu, flush=True)
-        sys.exit(1)
-    n_case += 1
-print(f'soak ok: {n_case} cases, max |phi - spsolve| = {worst:.2e} (range 0..1000, f32 output), worst residual of the '
-      f'f32 field in the reference system {worst_res:.1e}, iterations median {int(np.median(its))} max {max(its)}', flush=True)
+if __name__ == '__main__':
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.
+    t0 = time.time(); n_case = 0; worst = 0.0; its = []; worst_ratio = 0.0; worst_res = 0.0
+    master = np.random.default_rng(4242)
+    while time.time() - t0 < budget:
+        seed = int(master.integers(0, 2**31)); rng = np.random.default_rng(seed)
+        rows, cols = int(rng.integers(6, 90)), int(rng.integers(6, 110))
+        dirn = float(rng.choice([0., 45., 90., 135., 180., 225., 270., 315., -45., rng.uniform(0, 360)]))
+        cond = np.abs(rng.normal(0.8, 0.6, (rows, cols))) * 10.0 ** rng.uniform(-3, 1)
+        dead = rng.choice([0.0, 0.2, 0.5, 0.7])
+        cond[rng.random((rows, cols)) < dead] = 0.0
+        if rng.random() < 0.3:                                   # contiguous dead block
+            r0, c0 = int(rng.integers(0, rows - 3)), int(rng.integers(0, cols - 3))
+            cond[r0:r0 + rows // 3, c0:c0 + cols // 3] = 0.0
+        a_mat, b_vec, inodes, bnodes, benergy = assemble(cond, dirn)
+        x_ref = ssl.spsolve(a_mat, b_vec)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            pot, st = solve_potential(cond, dirn, rel_tol=float(os.environ.get('SOAK_TOL', '1e-15')), max_iterations=3000, return_stats=True)
+        x_gpu = np.asarray(pot, dtype=np.float64).T.reshape(-1)[inodes]          # node id = col * nrow + row
+        bn = np.linalg.norm(b_vec)
+        res_ref = np.linalg.norm(a_mat @ x_ref - b_vec) / bn
+        res_gpu = np.linalg.norm(a_mat @ x_gpu - b_vec) / bn                      # f32-rounded field!
+        err = float(np.abs(x_gpu - x_ref).max())
+        worst = max(worst, err); its.append(st['iterations']); worst_ratio = max(worst_ratio, res_gpu / max(res_ref, 1e-300))
+        worst_res = max(worst_res, res_gpu)
+        # the systems have condition numbers up to ~1e10, so the two answers may differ by more than
+        # an f32 ulp; what must hold is that ours solves the reference's system as well as an
+        # f32-rounded field can (residual of f32 rounding alone is ~1e-7)
+        if res_gpu > 1e-5 or err > float(os.environ.get('SOAK_ERR', '5e-3')):
+            print('MISMATCH', dict(seed=seed, rows=rows, cols=cols, dirn=dirn, dead=float(dead)), st, err, res_ref, res_gpu, flush=True)
+            sys.exit(1)
+        n_case += 1
+    print(f'soak ok: {n_case} cases, max |phi - spsolve| = {worst:.2e} (range 0..1000, f32 output), worst residual of the '
+          f'f32 field in the reference system {worst_res:.1e}, iterations median {int(np.median(its))} max {max(its)}', flush=True)
