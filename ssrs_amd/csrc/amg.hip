@@ -358,6 +358,53 @@ __device__ __forceinline__ double row_dot4(const int *__restrict__ rowptr, const
     return ax;
 }
 
+// kRowsPerGroup rows per 4-lane group, their loads issued together: with one row per group
+// a sweep is a chain of three dependent memory latencies (rowptr -> col / val -> x[col]) and
+// the occupancy limit (8192 waves) makes level 1 at 5000 x 6000 latency-bound (0.51 ms for
+// 1.4 GB); four independent chains per lane cover the latency.
+constexpr int kRowsPerGroup = 4;
+template <class V>
+__device__ __forceinline__ void rows_dot4(const int *__restrict__ rowptr, const int *__restrict__ col,
+                                          const V *__restrict__ val, const double *__restrict__ x,
+                                          const long long (&row)[kRowsPerGroup], int n, int sub,
+                                          double (&ax)[kRowsPerGroup])
+{
+    int p[kRowsPerGroup], end[kRowsPerGroup];
+#pragma unroll
+    for (int u = 0; u < kRowsPerGroup; ++u) {
+        const bool ok = row[u] < n;
+        p[u] = ok ? rowptr[row[u]] + sub : 0;
+        end[u] = ok ? rowptr[row[u] + 1] : 0;
+        ax[u] = 0.0;
+    }
+    // two entries per lane and row in flight (rows of up to 8 non-zeros: the common case)
+    int c0[kRowsPerGroup], c1[kRowsPerGroup];
+    double v0[kRowsPerGroup], v1[kRowsPerGroup];
+#pragma unroll
+    for (int u = 0; u < kRowsPerGroup; ++u) {
+        const bool a = p[u] < end[u], b = p[u] + kRowLanes < end[u];
+        c0[u] = a ? col[p[u]] : -1;
+        v0[u] = a ? static_cast<double>(val[p[u]]) : 0.0;
+        c1[u] = b ? col[p[u] + kRowLanes] : -1;
+        v1[u] = b ? static_cast<double>(val[p[u] + kRowLanes]) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < kRowsPerGroup; ++u) {
+        const double x0 = c0[u] >= 0 ? x[c0[u]] : 0.0;
+        const double x1 = c1[u] >= 0 ? x[c1[u]] : 0.0;
+        ax[u] += v0[u] * x0;
+        ax[u] += v1[u] * x1;
+    }
+#pragma unroll
+    for (int u = 0; u < kRowsPerGroup; ++u)                    // longer rows
+        for (int q = p[u] + 2 * kRowLanes; q < end[u]; q += kRowLanes) ax[u] += static_cast<double>(val[q]) * x[col[q]];
+#pragma unroll
+    for (int u = 0; u < kRowsPerGroup; ++u) {
+        ax[u] += __shfl_xor(ax[u], 1);
+        ax[u] += __shfl_xor(ax[u], 2);
+    }
+}
+
 template <class V>
 __global__ __launch_bounds__(kBlock) void k_jacobi4(const int *__restrict__ rowptr,
                                                    const int *__restrict__ col,
@@ -368,13 +415,18 @@ __global__ __launch_bounds__(kBlock) void k_jacobi4(const int *__restrict__ rowp
                                                    double *__restrict__ xn)
 {
     const int sub = threadIdx.x % kRowLanes;
-    const long long stride = static_cast<long long>(gridDim.x) * (kBlock / kRowLanes);
+    const long long groups = static_cast<long long>(gridDim.x) * (kBlock / kRowLanes);
     // whole groups stay in the loop together (the bound is per group, not per lane)
     for (long long i = blockIdx.x * static_cast<long long>(kBlock / kRowLanes) + threadIdx.x / kRowLanes; i < n;
-         i += stride) {
-        const int row = static_cast<int>(i);
-        const double ax = row_dot4(rowptr, col, val, x, row, sub);
-        if (sub == 0) xn[row] = x[row] + kOmega * dinv[row] * (b[row] - ax);
+         i += groups * kRowsPerGroup) {
+        long long row[kRowsPerGroup];
+        double ax[kRowsPerGroup];
+#pragma unroll
+        for (int u = 0; u < kRowsPerGroup; ++u) row[u] = i + u * groups;
+        rows_dot4(rowptr, col, val, x, row, n, sub, ax);
+#pragma unroll
+        for (int u = 0; u < kRowsPerGroup; ++u)
+            if (sub == 0 && row[u] < n) xn[row[u]] = x[row[u]] + kOmega * dinv[row[u]] * (b[row[u]] - ax[u]);
     }
 }
 
@@ -387,12 +439,17 @@ __global__ __launch_bounds__(kBlock) void k_residual4(const int *__restrict__ ro
                                                      double *__restrict__ r)
 {
     const int sub = threadIdx.x % kRowLanes;
-    const long long stride = static_cast<long long>(gridDim.x) * (kBlock / kRowLanes);
+    const long long groups = static_cast<long long>(gridDim.x) * (kBlock / kRowLanes);
     for (long long i = blockIdx.x * static_cast<long long>(kBlock / kRowLanes) + threadIdx.x / kRowLanes; i < n;
-         i += stride) {
-        const int row = static_cast<int>(i);
-        const double ax = row_dot4(rowptr, col, val, x, row, sub);
-        if (sub == 0) r[row] = b[row] - ax;
+         i += groups * kRowsPerGroup) {
+        long long row[kRowsPerGroup];
+        double ax[kRowsPerGroup];
+#pragma unroll
+        for (int u = 0; u < kRowsPerGroup; ++u) row[u] = i + u * groups;
+        rows_dot4(rowptr, col, val, x, row, n, sub, ax);
+#pragma unroll
+        for (int u = 0; u < kRowsPerGroup; ++u)
+            if (sub == 0 && row[u] < n) r[row[u]] = b[row[u]] - ax[u];
     }
 }
 
@@ -982,7 +1039,7 @@ static void launch_jacobi(AmgHierarchy &h, size_t lev, const double *x, double *
         const L0Stencil a{h.l0_rinv, h.l0_fixed, h.l0_rows, h.l0_cols};
         hipLaunchKernelGGL(k_l0_jacobi, l0_grid(h), dim3(kBlock), 0, st, a, L.dinv, L.b, x, xn);
     } else {
-        const dim3 g4(grid_for(static_cast<size_t>(L.n) * kRowLanes)), g1(grid_for(L.n));
+        const dim3 g4(grid_for((static_cast<size_t>(L.n) + kRowsPerGroup - 1) / kRowsPerGroup * kRowLanes)), g1(grid_for(L.n));
         if (L.n >= kVectorRows && L.val32)
             hipLaunchKernelGGL(k_jacobi4<float>, g4, dim3(kBlock), 0, st, L.rowptr, L.col, L.val32, L.dinv, L.b, x, L.n, xn);
         else if (L.n >= kVectorRows)
@@ -1001,7 +1058,7 @@ static void launch_residual(AmgHierarchy &h, size_t lev, hipStream_t st)
         const L0Stencil a{h.l0_rinv, h.l0_fixed, h.l0_rows, h.l0_cols};
         hipLaunchKernelGGL(k_l0_residual, l0_grid(h), dim3(kBlock), 0, st, a, L.b, L.x, L.r);
     } else {
-        const dim3 g4(grid_for(static_cast<size_t>(L.n) * kRowLanes)), g1(grid_for(L.n));
+        const dim3 g4(grid_for((static_cast<size_t>(L.n) + kRowsPerGroup - 1) / kRowsPerGroup * kRowLanes)), g1(grid_for(L.n));
         if (L.n >= kVectorRows && L.val32)
             hipLaunchKernelGGL(k_residual4<float>, g4, dim3(kBlock), 0, st, L.rowptr, L.col, L.val32, L.b, L.x, L.n, L.r);
         else if (L.n >= kVectorRows)
