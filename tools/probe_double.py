@@ -1,4 +1,5 @@
-"""Single vs double pairwise aggregation on small rasters: iterations / residual (SSRS_AMG_DOUBLE)."""
+"""Solver on small speckled rasters: iterations / residual.  (Was the A/B of the double pairwise
+aggregation experiment, profiles/r01_notes.md; the SSRS_AMG_DOUBLE switch went with the revert.)"""
 import os, sys, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
