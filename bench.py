@@ -48,6 +48,10 @@ def parse():
                     help='target CPU time of the cpu_baseline sample (0 = skip)')
     ap.add_argument('--potential', default='ramp', choices=['ramp', 'solve'])
     ap.add_argument('--solve-iterations', type=int, default=2000)
+    ap.add_argument('--solved-tracks', type=int, default=10_000,
+                    help='tracks of the solved_potential leg (outside the timed region; 0 = skip)')
+    ap.add_argument('--ref-cpu-tracks', type=int, default=3,
+                    help='tracks of the reference-equivalent (numpy restatement) CPU rate (0 = skip)')
     ap.add_argument('--no-binning', action='store_true', help='per-step global atomics for the histogram')
     ap.add_argument('--no-schedule', action='store_true', help='disable the coherent schedule')
     ap.add_argument('--exact-only', action='store_true', help='disable the fast decision path')
@@ -79,8 +83,27 @@ def cpu_baseline(args, gridsize, dem, pot, starts, seed, steps_per_track):
     run = c_oracle.simulate_tracks(0.0, starts[:m], gridsize, 1, 1.0, upd, pot, seed=seed,
                                    want_traj=False, want_hist=True, nthreads=cores)
     t_run = time.perf_counter() - t0
+    ref_equiv = None
+    if args.ref_cpu_tracks > 0:
+        # the reference's own arithmetic speed: the numpy restatement (oracle/ssrs_oracle.py, the
+        # same per-step numpy calls as /root/reference/ssrs/movmodel.py:264-318, which cannot travel)
+        from oracle import ssrs_oracle as orc
+        from oracle.philox import TrackUniforms
+        t0 = time.perf_counter()
+        nsteps = 0
+        for t in range(args.ref_cpu_tracks):
+            tr = orc.generate_simulated_tracks(0.0, (int(starts[t, 0]), int(starts[t, 1])), gridsize, 1, 1.0,
+                                               upd, pot, uniform=TrackUniforms(seed, t))
+            nsteps += len(tr) - 1
+            assert len(tr) == run['lengths'][t], 'numpy restatement and C port disagree'
+        t_ref = time.perf_counter() - t0
+        ref_equiv = {'steps_per_s_per_core': nsteps / t_ref, 'cores': 1, 'tracks': args.ref_cpu_tracks,
+                     'steps': nsteps, 'seconds': t_ref,
+                     'what': 'numpy restatement of generate_simulated_tracks, one process, first tracks of '
+                             'this workload; SURVEY measured 12.1 k steps/s/core for the reference itself'}
     return {
         'value': m / t_run, 'unit': 'tracks/s', 'cores': cores, 'kind': 'port',
+        'reference_equivalent': ref_equiv,
         'sample': (f'C/OpenMP oracle port, first {m} of the {len(starts)} tracks of this '
                    f'workload ({run["steps"]} steps in {t_run:.1f} s) on {cores} host threads; '
                    f'raster chain on the full grid once ({t_raster:.1f} s)'),
@@ -88,6 +111,75 @@ def cpu_baseline(args, gridsize, dem, pot, starts, seed, steps_per_track):
         'steps_per_s_per_core': run['steps'] / t_run / cores,
         'raster_mcells_per_s': gridsize[0] * gridsize[1] / t_raster / 1e6,
     }, run, m
+
+
+def chain_probe(args, movmodel, layers, dem, pot, starts_h, gridsize, res, seed):
+    """What bounds the stepper: one step of a track is a chain of dependent instructions
+    (Philox -> decision -> next address -> 12-byte gather -> ...).  A batch of 16 384 tracks is
+    one wave per CU, nothing to overlap with: launch time / steps = the chain's latency.  The
+    full batch (1.5 waves per SIMD) cannot run a launch faster than S x that latency."""
+    import torch
+    _, upd = layers.updraft_from_dem(dem, res, 10.0, 270.0, threshold=0.75)
+    table = movmodel.build_transition_table(upd, pot, ring=not (args.f64_table or args.exact_only))
+    n = 16384
+    sub = torch.from_numpy(starts_h[:n]).to(dem.device)
+    best = None
+    for _ in range(3):
+        o = movmodel.simulate_tracks(0.0, sub, gridsize, 1, 1.0, upd, pot, seed=seed, table=table,
+                                     profile=True, exact_only=args.exact_only, want_hist=False)
+        L = o.lengths.cpu().numpy() - 1
+        S = args.steps_per_launch or 512
+        full = int(np.min(L)) // S                    # launches in which every track steps all S times
+        if full < 1:
+            continue
+        # kernel_ms covers all launches; the first `full` ones are S steps deep for every wave
+        us = o.stats['kernel_ms'] * 1e3 / o.stats['launches'] / S
+        best = us if best is None else min(best, us)
+    return {'tracks': n, 'us_per_step_lone_wave': best,
+            'launch_floor_ms': None if best is None else best * (args.steps_per_launch or 512) / 1e3,
+            'what': 'average launch duration / steps per launch of a 16 384-track batch (one wave per CU, no '
+                    'histogram): the latency of one step\'s dependent chain, an upper bound (late launches are '
+                    'shallower than S steps)'}
+
+
+def solved_leg(args, movmodel, layers, dem, starts_h, gridsize, res, seed):
+    """The same workload on the potential of the build's own solver, outside the
+    timed region and on a bounded batch: on this DEM about 44 % of the tracks reach a basin of
+    the field, circle there and stop at max_moves = 7.5e6 (reference behaviour, pinned at 50 m by
+    tests/golden/g11_wander.npz), so 100k tracks take ~12 s per pass."""
+    import torch
+    import warnings
+    from ssrs_amd.potential import solve_potential
+    _, upd = layers.updraft_from_dem(dem, res, 10.0, 270.0, threshold=0.75)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        pot, sst = solve_potential(upd, 0.0, max_iterations=args.solve_iterations, return_stats=True)
+    torch.cuda.synchronize()
+    t_solve = time.perf_counter() - t0
+    n = min(args.solved_tracks, len(starts_h))
+    sub = torch.from_numpy(starts_h[:n]).to(dem.device)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    table = movmodel.build_transition_table(upd, pot, ring=True)
+    o = movmodel.simulate_tracks(0.0, sub, gridsize, 1, 1.0, upd, pot, seed=seed, table=table, profile=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    L = o.lengths.cpu().numpy() - 1
+    mm = gridsize[0] // 2 * (gridsize[1] // 2)
+    assert int(o.hist.sum().item()) == o.stats['total_steps'] + n, 'histogram checksum failed (solved leg)'
+    return {
+        'tracks': n, 'tracks_per_s': n / dt, 'steps_per_s': o.stats['total_steps'] / dt, 'seconds': dt,
+        'steps_per_track_mean': float(L.mean()), 'steps_per_track_median': float(np.median(L)),
+        'steps_per_track_max': int(L.max()), 'share_at_max_moves': float(np.mean(L >= mm)), 'max_moves': mm,
+        'launches': o.stats['launches'], 'window_launches': o.stats['window_launches'],
+        'tile_launches': o.stats['tile_launches'],
+        'solver': {'iterations': sst['iterations'], 'residual': sst['residual'], 'converged': sst['converged'],
+                   'seconds': t_solve, 'rel_tol': 1e-15, 'amg_levels': sst['amg_levels']},
+        'what': 'first tracks of the same start list through ssrs_potential_solve\'s field (library default '
+                'tolerance), one pass, table build included; not part of `value`',
+    }
 
 
 def main():
@@ -144,8 +236,8 @@ def main():
         import warnings
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
-            pot, sst = solve_potential(upd0, 0.0, rel_tol=1e-8, max_iterations=args.solve_iterations,
-                                       return_stats=True)
+            pot, sst = solve_potential(upd0, 0.0, max_iterations=args.solve_iterations,
+                                       return_stats=True)      # library default rel_tol (1e-15)
         pot_label = (f'ssrs_potential_solve (AMG-PCG): {sst["iterations"]} iterations, |r|/|b| = '
                      f'{sst["residual"]:.1e}, {sst["kernel_ms"] / 1e3:.0f} s (outside the timed region)')
         del upd0
@@ -241,6 +333,7 @@ def main():
     # bytes the chosen data path really requests per step (read + 4 B visit / histogram update)
     moved_bytes = 76 if args.direct else (92 if args.exact_only else (28 if args.f64_table else 16))
     achieved = acc['steps'] * STEP_BYTES / kernel_s / 1e9 if kernel_s > 0 else 0.0
+    moved_gbps = acc['steps'] * moved_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0
     raster_s = acc['raster_ms'] / 1e3 / K
     out = {
         'metric': 'simulated tracks/sec (whole node)',
@@ -281,31 +374,45 @@ def main():
         'roofline': {
             'kernel': ('k_step_tracks' if (args.direct or args.f64_table or args.exact_only)
                        else 'k_step_lean<ring>') + ' (K2 stepper, rank 0)',
-            'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-            'frac': achieved / HBM_PEAK_GBPS,
+            # what bounds it: the dependent chain of one step (see dependent_chain below and
+            # profiles/r02_stepper_chain.md), not HBM: the kernel moves 16 B per step
+            'bound': 'latency',
+            # achieved = bytes the shipped data path really requests per step (one 12-byte triple of
+            # the f32 ring table + the 4-byte visit) x steps / sum of the stepper launch durations
+            'achieved': moved_gbps, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+            'frac': moved_gbps / HBM_PEAK_GBPS,
             'traffic': None,
-            'algorithmic_bytes_per_step': STEP_BYTES,
+            'bytes_per_step': moved_bytes,
             'launches': acc['launches'] // K,
             'avg_launch_ms': acc['step_kernel_ms'] / max(acc['launches'], 1),
-            'avg_bytes_per_launch': acc['steps'] * STEP_BYTES / max(acc['launches'], 1),
-            # the 76 B/step of SURVEY 8(d) is the gather volume of the reference's formulation
-            # (18 window reads + 1 point); the shipped path precomputes the windows into a table
-            # and moves MOVED_BYTES per step, so a model fraction near or above 1 does NOT mean
-            # HBM is saturated: the kernel is bound by the dependent chain of a step
-            'moved_bytes_per_step': moved_bytes,
-            'moved_gbps': acc['steps'] * moved_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0,
-            'moved_frac': (acc['steps'] * moved_bytes / kernel_s / 1e9 / HBM_PEAK_GBPS) if kernel_s > 0 else 0.0,
+            'avg_bytes_per_launch': acc['steps'] * moved_bytes / max(acc['launches'], 1),
+            # SURVEY 8(d)'s 76 B/step is the gather volume of the REFERENCE's formulation (18 window
+            # reads + 1 point); the shipped path precomputes the windows into a table, so this
+            # figure can exceed the peak and is not a roofline fraction
+            'model_bytes_per_step': STEP_BYTES,
+            'model_gbps': achieved,
+            'model_frac': achieved / HBM_PEAK_GBPS,
         },
     }
+    # HBM bytes per launch from the PMC passes (profiles/, separate --pmc runs): only quoted when
+    # THIS run is the configuration those passes profiled
     pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-    if os.path.exists(pmc):
+    default_variant = (world == 1 and args.potential == 'ramp' and not (args.direct or args.f64_table or args.exact_only
+                       or args.no_binning or args.no_schedule) and args.tracks == 100_000 and res == 10.0
+                       and args.steps_per_launch in (0, 512) and args.dem_noise == 1.5)
+    if os.path.exists(pmc) and default_variant:
         try:
             with open(pmc) as f:
                 rec = json.load(f)
             out['roofline']['traffic'] = rec.get('k_step_tracks_bytes_per_launch')
-            out['roofline']['traffic_source'] = rec.get('source')
+            out['roofline']['traffic_source'] = ('profile constant (not counted in this run): '
+                                                 + str(rec.get('source')))
         except Exception:
             pass
+    if world == 1 and not args.direct:
+        out['roofline']['dependent_chain'] = chain_probe(args, movmodel, layers, dem, pot, starts_h, gridsize, res, seed)
+    if world == 1 and args.solved_tracks > 0 and args.potential != 'solve':
+        out['solved_potential'] = solved_leg(args, movmodel, layers, dem, starts_h, gridsize, res, seed)
     if world == 1 and args.cpu_seconds > 0:
         cpu, run, m = cpu_baseline(args, gridsize, dem_h, pot.cpu().numpy(), starts_h, seed,
                                    steps_per_track)

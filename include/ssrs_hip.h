@@ -253,6 +253,39 @@ int ssrs_tracks_simulate(const SsrsTrackParams *params, const double *updraft,
                          size_t workspace_bytes, SsrsTrackStats *stats,
                          void *stream);
 
+/* Trajectory output in ONE simulation pass (the List[int16 (n_i, 2)] that
+ * Simulator.simulate_tracks pickles, simulator.py:360-385).  The two-call form above needs
+ * the lengths of an earlier identical simulation for `traj_offsets`.  With a recorder the
+ * stepper keeps every launch's visited cells in a caller-supplied device pool (4 bytes per
+ * step and live slot); when the call returns the lengths are final, the caller forms the
+ * offsets (exclusive prefix sums of `lengths`), allocates `traj` and ssrs_tracks_gather
+ * appends every track's points in order.  Every stepper path (ring table included) records.
+ *   pool        device scratch, 256-byte aligned; when it is exhausted the simulation goes
+ *               on unrecorded (results unaffected), ssrs_traj_recorder_complete() returns 0
+ *               and the caller falls back to the two-call form or a larger pool
+ *   recorder    reusable: each ssrs_tracks_simulate_rec call starts a fresh record */
+typedef struct SsrsTrajRecorder SsrsTrajRecorder;
+SsrsTrajRecorder *ssrs_traj_recorder_create(void *pool, size_t pool_bytes);
+void ssrs_traj_recorder_destroy(SsrsTrajRecorder *recorder);
+int ssrs_traj_recorder_complete(const SsrsTrajRecorder *recorder);
+size_t ssrs_traj_recorder_used(const SsrsTrajRecorder *recorder);
+/* ssrs_tracks_simulate without traj / traj_offsets, recording into `recorder` */
+int ssrs_tracks_simulate_rec(const SsrsTrackParams *params, const double *updraft,
+                             const float *potential, const double *table,
+                             const int32_t *start_rc, int64_t ntracks, uint64_t seed,
+                             uint64_t track_id_base, uint32_t *hist, int16_t *end_rc,
+                             int32_t *lengths, SsrsTrajRecorder *recorder, void *workspace,
+                             size_t workspace_bytes, SsrsTrackStats *stats, void *stream);
+/* traj[2 * traj_offsets[t] ...] <- the int16 (row, col) points of track t, start cell first
+ * (asynchronous on `stream`; the pool must stay alive until it has run).
+ *   start_rc, ntracks   as passed to ssrs_tracks_simulate_rec
+ *   traj_offsets        int64 (ntracks + 1), exclusive prefix sums of `lengths`; points
+ *                       beyond a track's room are dropped, never written
+ *   cursor_ws           device scratch, 4 bytes per track */
+int ssrs_tracks_gather(const SsrsTrajRecorder *recorder, const int32_t *start_rc,
+                       int64_t ntracks, const int64_t *traj_offsets, int16_t *traj,
+                       void *cursor_ws, size_t cursor_bytes, void *stream);
+
 /* --------------------------------------------------------------- presence */
 
 /* compute_presence_counts (ssrs/movmodel.py:410-419) from stored trajectories:
@@ -272,6 +305,13 @@ size_t ssrs_presence_workspace_bytes(int rows, int cols, int krad);
 int ssrs_presence_smooth(const uint32_t *count, int krad, float *out, int rows,
                          int cols, void *workspace, size_t workspace_bytes,
                          void *stream);
+
+/* The same for 64-bit counts: the sum of the ranks' histograms when a 32-bit sum could wrap
+ * (tracks that circle in a pocket of the field until max_moves put ~1e9 visits into single
+ * cells per 100k tracks).  The chord sums are 64-bit either way. */
+int ssrs_presence_smooth_u64(const uint64_t *count, int krad, float *out, int rows,
+                             int cols, void *workspace, size_t workspace_bytes,
+                             void *stream);
 
 /* The normalisation ladder of Simulator.plot_presence_map (simulator.py:529-546):
  *   acc += src / max(src)     (division in src's precision: f32 for `prprob`,

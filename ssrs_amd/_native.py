@@ -29,7 +29,10 @@ EXPORTS = (
     'ssrs_gaussian_blur', 'ssrs_track_params_init', 'ssrs_transition_table_build',
     'ssrs_transition_ring_bytes', 'ssrs_transition_ring_build',
     'ssrs_tracks_workspace_bytes', 'ssrs_tracks_workspace_bytes_ex', 'ssrs_tracks_simulate', 'ssrs_uniform_selftest',
+    'ssrs_traj_recorder_create', 'ssrs_traj_recorder_destroy', 'ssrs_traj_recorder_complete',
+    'ssrs_traj_recorder_used', 'ssrs_tracks_simulate_rec', 'ssrs_tracks_gather',
     'ssrs_presence_count', 'ssrs_presence_workspace_bytes', 'ssrs_presence_smooth',
+    'ssrs_presence_smooth_u64',
     'ssrs_presence_normalise_add', 'ssrs_presence_normalise_f32',
     'ssrs_potential_workspace_bytes', 'ssrs_potential_solve',
 )
@@ -80,6 +83,13 @@ def lib():
         L.ssrs_lattice_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
         L.ssrs_tracks_workspace_bytes_ex.restype = C.c_size_t
         L.ssrs_tracks_workspace_bytes_ex.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int]
+        L.ssrs_traj_recorder_create.restype = C.c_void_p
+        L.ssrs_traj_recorder_create.argtypes = [C.c_void_p, C.c_size_t]
+        L.ssrs_traj_recorder_destroy.restype = None
+        L.ssrs_traj_recorder_destroy.argtypes = [C.c_void_p]
+        L.ssrs_traj_recorder_complete.argtypes = [C.c_void_p]
+        L.ssrs_traj_recorder_used.restype = C.c_size_t
+        L.ssrs_traj_recorder_used.argtypes = [C.c_void_p]
         L.ssrs_transition_ring_bytes.restype = C.c_size_t
         L.ssrs_transition_ring_bytes.argtypes = [C.c_int, C.c_int]
         if hasattr(L, 'ssrs_presence_workspace_bytes'):

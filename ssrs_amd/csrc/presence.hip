@@ -37,13 +37,14 @@ __global__ __launch_bounds__(kBlock) void k_presence_count(const int16_t *__rest
 }
 
 // exclusive prefix sums of one raster row per block: P[r][0..cols]
-__global__ __launch_bounds__(kBlock) void k_row_prefix(const uint32_t *__restrict__ count,
+template <typename CountT>
+__global__ __launch_bounds__(kBlock) void k_row_prefix(const CountT *__restrict__ count,
                                                       unsigned long long *__restrict__ prefix,
                                                       int rows, int cols)
 {
     __shared__ unsigned long long part[kBlock];
     const int r = blockIdx.x;
-    const uint32_t *row = count + static_cast<size_t>(r) * cols;
+    const CountT *row = count + static_cast<size_t>(r) * cols;
     unsigned long long *out = prefix + static_cast<size_t>(r) * (cols + 1);
     const int chunk = (cols + kBlock - 1) / kBlock;
     const int lo = threadIdx.x * chunk;
@@ -170,9 +171,9 @@ extern "C" int ssrs_presence_count(const int16_t *traj, int64_t npoints, uint32_
     return SSRS_OK;
 }
 
-extern "C" int ssrs_presence_smooth(const uint32_t *count, int krad, float *out, int rows,
-                                    int cols, void *workspace, size_t workspace_bytes,
-                                    void *stream)
+template <typename CountT>
+static int presence_smooth(const CountT *count, int krad, float *out, int rows, int cols,
+                           void *workspace, size_t workspace_bytes, void *stream)
 {
     SSRS_REQUIRE(count && out && workspace, "ssrs_presence_smooth: NULL pointer");
     SSRS_REQUIRE(rows > 0 && cols > 0 && krad >= 0, "ssrs_presence_smooth: bad sizes");
@@ -198,13 +199,28 @@ extern "C" int ssrs_presence_smooth(const uint32_t *count, int krad, float *out,
     SSRS_HIP_CHECK(hipMemcpyAsync(d_half, half.data(), half.size() * sizeof(int),
                                   hipMemcpyHostToDevice, st));
     SSRS_HIP_CHECK(hipStreamSynchronize(st));   // `half` is a host temporary
-    hipLaunchKernelGGL(k_row_prefix, dim3(rows), dim3(kBlock), 0, st, count, prefix, rows, cols);
+    hipLaunchKernelGGL(k_row_prefix<CountT>, dim3(rows), dim3(kBlock), 0, st, count, prefix, rows, cols);
     SSRS_HIP_CHECK(hipGetLastError());
     const double weight = 1.0 / static_cast<double>(ntaps);   // kernel /= np.sum(kernel)
     hipLaunchKernelGGL(k_disk_sum, dim3((cols + kBlock - 1) / kBlock, rows), dim3(kBlock), 0, st,
                        prefix, d_half, krad, weight, out, rows, cols);
     SSRS_HIP_CHECK(hipGetLastError());
     return SSRS_OK;
+}
+
+extern "C" int ssrs_presence_smooth(const uint32_t *count, int krad, float *out, int rows,
+                                    int cols, void *workspace, size_t workspace_bytes,
+                                    void *stream)
+{
+    return presence_smooth<uint32_t>(count, krad, out, rows, cols, workspace, workspace_bytes, stream);
+}
+
+extern "C" int ssrs_presence_smooth_u64(const uint64_t *count, int krad, float *out, int rows,
+                                        int cols, void *workspace, size_t workspace_bytes,
+                                        void *stream)
+{
+    return presence_smooth<unsigned long long>(reinterpret_cast<const unsigned long long *>(count), krad, out,
+                                               rows, cols, workspace, workspace_bytes, stream);
 }
 
 extern "C" int ssrs_presence_normalise_add(const void *src, int src_type, double *acc, size_t n,

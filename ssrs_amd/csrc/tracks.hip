@@ -38,6 +38,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <vector>
 
 #include "common.h"
@@ -626,6 +627,8 @@ struct StepArgs {
     uint32_t *visits;            // [steps][visit_stride] visited cell per slot (K3 binning), or NULL
     long long visit_stride;
     uint32_t cap;                // slots per XCD list (multiple of kBlock); list x = [x*cap, (x+1)*cap)
+    uint32_t vcap;               // slots per XCD list in the visit buffer (= cap, or the launch's own
+                                 // bound when its visits are recorded for trajectory output)
     const double *thr;           // [9][9] prior-fallback thresholds (k_prior_thresholds)
     const uint8_t *zmask;        // ring table's zero-mask bytes (scattered variant), or NULL
     uint32_t *hist_copies;       // privatised histogram copies (scattered batches), or NULL
@@ -692,6 +695,7 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
     const uint32_t nlive = ctl->count[in_slot][xcd];
     const uint32_t il = (blockIdx.x / kXcd) * kBlock + threadIdx.x;   // position in list xcd
     const uint32_t i = xcd * a.cap + il;                               // slot in the list arrays
+    const uint32_t iv = xcd * a.vcap + il;                             // slot in the visit buffer
     if (blockIdx.x == 0 && threadIdx.x < kXcd)
         ctl->count[(a.launch + 2) & 3][threadIdx.x] = 0;   // free slot of launch+1's output
     // whole waves past the live list leave at once (wave-uniform)
@@ -851,7 +855,7 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
         //    per-step atomics the stepper's limit: 10.6 ms vs 6.3 ms without)
         //  * fallback: one atomic per lane (idle lanes add 0 to their own cell)
         if (a.visits) {
-            a.visits[static_cast<long long>(it) * a.visit_stride + i] =
+            a.visits[static_cast<long long>(it) * a.visit_stride + iv] =
                 stepped ? __umul24(static_cast<uint32_t>(row), a.vis_r) + __umul24(static_cast<uint32_t>(col), a.vis_c)
                         : 0xFFFFFFFFu;
         } else if (a.hist) {
@@ -866,7 +870,7 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
     // a wave that ran out of live lanes early still owns its slots of the buffer
     if (a.visits)
         for (int it = last_it + 1; it < a.steps; ++it)
-            a.visits[static_cast<long long>(it) * a.visit_stride + i] = 0xFFFFFFFFu;
+            a.visits[static_cast<long long>(it) * a.visit_stride + iv] = 0xFFFFFFFFu;
 
     // ---- wave-level compaction of the survivors into the next launch's list
     const unsigned long long live = __ballot(active);
@@ -979,6 +983,7 @@ __global__ __launch_bounds__(kBlock) void k_step_lean(const StepArgs a)
     const uint32_t nlive = ctl->count[in_slot][xcd];
     const uint32_t il = (blockIdx.x / kXcd) * kBlock + threadIdx.x;
     const uint32_t i = xcd * a.cap + il;
+    const uint32_t iv = xcd * a.vcap + il;
     if (blockIdx.x == 0 && threadIdx.x < kXcd) ctl->count[(a.launch + 2) & 3][threadIdx.x] = 0;
     if ((il & ~63u) >= nlive) return;
 
@@ -1160,7 +1165,7 @@ __global__ __launch_bounds__(kBlock) void k_step_lean(const StepArgs a)
             const uint32_t key = VT ? __umul24(static_cast<uint32_t>(col), static_cast<uint32_t>(a.rows)) +
                                           static_cast<uint32_t>(row)
                                     : cell;
-            a.visits[static_cast<long long>(it) * a.visit_stride + i] = st ? key : 0xFFFFFFFFu;
+            a.visits[static_cast<long long>(it) * a.visit_stride + iv] = st ? key : 0xFFFFFFFFu;
         } else if (a.hist) {
             uint32_t *h = a.hist;
             // scattered variant: wave-private copy, so that same-address atomics of
@@ -1179,7 +1184,7 @@ __global__ __launch_bounds__(kBlock) void k_step_lean(const StepArgs a)
     }
     if (a.visits)
         for (int it = last_it + 1; it < a.steps; ++it)
-            a.visits[static_cast<long long>(it) * a.visit_stride + i] = 0xFFFFFFFFu;
+            a.visits[static_cast<long long>(it) * a.visit_stride + iv] = 0xFFFFFFFFu;
 
     // tracks that finished in this launch
     if (was_active && !active) {
@@ -1599,6 +1604,88 @@ __global__ __launch_bounds__(kBlock) void k_transpose_add(const uint32_t *__rest
     }
 }
 
+
+// ------------------------------------------------------------ trajectory record
+// Trajectory output without a second simulation pass.  The stepper already writes the
+// cell every slot visits at every step of a launch into the visit buffer (the input of
+// the binning kernels).  With a recorder each launch gets its OWN region of a caller-
+// supplied pool -- [8 list counts][the launch's slot -> track list][visits of S steps] --
+// instead of the shared buffer, and once the lengths are final (they give the offsets)
+// ssrs_tracks_gather replays the regions in launch order and appends every track's
+// visits at its cursor.  4 B written per step while stepping, 4 B read + 4 B written
+// in the gather; the ring stepper stays in use (the generic kernel's direct trajectory
+// writes needed the lengths of an earlier pass: two full simulations).
+struct TrajChunk {
+    const uint32_t *counts;      // [kXcd] live slots per list when the launch started
+    const int32_t *list;         // [kXcd][vcap] slot -> track, nullptr = identity over `cap`
+    const uint32_t *visits;      // [steps][kXcd * vcap]
+    uint32_t vcap, cap;
+    int steps;
+    int transposed;              // visit key = col * rows + row (east / west fronts)
+};
+
+// plain per-visit atomics: the histogram of a recorded launch that neither binning path took
+__global__ __launch_bounds__(kBlock) void k_count_visits(const uint32_t *__restrict__ visits, uint32_t vcap,
+                                                        int steps, const uint32_t *__restrict__ counts,
+                                                        uint32_t *__restrict__ hist, uint32_t ncell)
+{
+    const uint32_t x = blockIdx.x % kXcd, j = (blockIdx.x / kXcd) * kBlock + threadIdx.x;
+    const uint32_t nslots = (counts[x] + 63u) & ~63u;
+    if (j >= nslots) return;
+    const uint32_t *v = visits + static_cast<size_t>(x) * vcap + j;
+    const size_t stride = static_cast<size_t>(kXcd) * vcap;
+    for (int it = 0; it < steps; ++it) {
+        const uint32_t c = v[it * stride];
+        if (c < ncell) atomicAdd(&hist[c], 1u);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_gather_init(const int32_t *__restrict__ start_rc, long long ntracks,
+                                                       const long long *__restrict__ off, int16_t *__restrict__ traj,
+                                                       uint32_t *__restrict__ cursor)
+{
+    const long long t = blockIdx.x * static_cast<long long>(kBlock) + threadIdx.x;
+    if (t >= ntracks) return;
+    cursor[t] = 1;
+    if (off[t + 1] - off[t] > 0)
+        reinterpret_cast<uint32_t *>(traj)[off[t]] =
+            static_cast<uint32_t>(start_rc[2 * t] & 0xFFFF) | (static_cast<uint32_t>(start_rc[2 * t + 1]) << 16);
+}
+
+__global__ __launch_bounds__(kBlock) void k_gather_chunk(const TrajChunk ch, uint32_t rows, uint32_t cols,
+                                                        const long long *__restrict__ off,
+                                                        int16_t *__restrict__ traj, uint32_t *__restrict__ cursor)
+{
+    const uint32_t x = blockIdx.x % kXcd, j = (blockIdx.x / kXcd) * kBlock + threadIdx.x;
+    if (j >= ch.counts[x]) return;               // slots past the live list hold no visits
+    const uint32_t t = ch.list ? static_cast<uint32_t>(ch.list[static_cast<size_t>(x) * ch.vcap + j]) : x * ch.cap + j;
+    const long long base = off[t];
+    const long long room = off[t + 1] - base;    // never write beyond the track's room
+    uint32_t *out = reinterpret_cast<uint32_t *>(traj) + base;
+    uint32_t c = cursor[t];
+    const uint32_t ncell = rows * cols;
+    const uint32_t div = ch.transposed ? rows : cols;
+    const double inv = 1.0 / static_cast<double>(div);
+    const uint32_t *v = ch.visits + static_cast<size_t>(x) * ch.vcap + j;
+    const size_t stride = static_cast<size_t>(kXcd) * ch.vcap;
+    constexpr int kU = 8;
+    for (int it = 0; it < ch.steps; it += kU) {
+        uint32_t key[kU];
+#pragma unroll
+        for (int q = 0; q < kU; ++q) key[q] = it + q < ch.steps ? v[(it + q) * stride] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int q = 0; q < kU; ++q) {
+            if (key[q] >= ncell) continue;
+            uint32_t hi, lo;                     // key = hi * div + lo
+            split_cell(key[q], div, inv, hi, lo);
+            const uint32_t row = ch.transposed ? lo : hi, col = ch.transposed ? hi : lo;
+            if (c < room) out[c] = row | (col << 16);
+            ++c;
+        }
+    }
+    cursor[t] = c;
+}
+
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Workspace {
@@ -1678,6 +1765,21 @@ static uint32_t *pinned_counts()
     return buf;
 }
 
+
+}  // namespace ssrs
+
+// the opaque handle of include/ssrs_hip.h: a bump allocator over the caller's pool plus
+// the host-side directory of the launches recorded into it
+struct SsrsTrajRecorder {
+    char *pool;
+    size_t bytes, used;
+    std::vector<ssrs::TrajChunk> chunks;
+    int complete;                // 1: every launch of the last simulation is in `chunks`
+    int rows, cols;
+    long long ntracks;
+};
+
+namespace ssrs {
 }  // namespace ssrs
 
 using namespace ssrs;
@@ -1760,13 +1862,13 @@ extern "C" int ssrs_uniform_selftest(uint64_t seed, const uint64_t *track, const
     return SSRS_OK;
 }
 
-extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updraft,
-                                    const float *potential, const double *table,
-                                    const int32_t *start_rc, int64_t ntracks, uint64_t seed,
-                                    uint64_t track_id_base, uint32_t *hist, int16_t *end_rc,
-                                    int32_t *lengths, int16_t *traj, const int64_t *traj_offsets,
-                                    void *workspace, size_t workspace_bytes,
-                                    SsrsTrackStats *stats, void *stream)
+static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
+                                const float *potential, const double *table,
+                                const int32_t *start_rc, int64_t ntracks, uint64_t seed,
+                                uint64_t track_id_base, uint32_t *hist, int16_t *end_rc,
+                                int32_t *lengths, int16_t *traj, const int64_t *traj_offsets,
+                                void *workspace, size_t workspace_bytes,
+                                SsrsTrackStats *stats, void *stream, SsrsTrajRecorder *rec)
 {
     SSRS_REQUIRE(p != nullptr, "ssrs_tracks_simulate: params is NULL");
     SSRS_REQUIRE(p->rows >= 5 && p->cols >= 5, "ssrs_tracks_simulate: need rows, cols >= 5 (got %d x %d)",
@@ -1786,6 +1888,14 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
     SSRS_REQUIRE(!(table && (reinterpret_cast<uintptr_t>(table) & 63u)),
                  "ssrs_tracks_simulate: table must be 64-byte aligned");
     if (stats) *stats = SsrsTrackStats{};
+    if (rec) {
+        rec->used = 0;
+        rec->chunks.clear();
+        rec->complete = 1;
+        rec->rows = p->rows;
+        rec->cols = p->cols;
+        rec->ntracks = ntracks;
+    }
     if (ntracks == 0) return SSRS_OK;
     SSRS_REQUIRE(start_rc != nullptr, "ssrs_tracks_simulate: start_rc is NULL");
     SSRS_REQUIRE(workspace && workspace_bytes >= ssrs_tracks_workspace_bytes(ntracks),
@@ -1854,6 +1964,7 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
     a.cap = ws.cap;
     a.thr = ws.thr;
     hipLaunchKernelGGL(k_prior_thresholds, dim3(1), dim3(64), 0, st, ws.ctl->prior, ws.thr);
+    a.vcap = ws.cap;
     const bool lean = p->memory_parameter == 1 && traj == nullptr;
     const bool ring = (p->flags & SSRS_TRACKS_RING_TABLE) != 0;
     if (ring)
@@ -1945,6 +2056,43 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
                 a.ncopies = ncopies;
             }
             if (binning_on || tiles_on) a.visits = ws.visits;
+            a.visit_stride = ws.visit_stride;
+            a.vcap = ws.cap;
+            const uint32_t *rec_counts = nullptr;
+            if (rec && rec->complete) {
+                // this launch's own region of the pool: [counts][slot -> track list][visits]
+                const uint32_t vcap = (blocks / kXcd) * kBlock;
+                const bool identity = a.list_in == nullptr;
+                const size_t list_bytes = identity ? 0 : align_up(sizeof(int32_t) * kXcd * static_cast<size_t>(vcap), 256);
+                const size_t vis_bytes = align_up(sizeof(uint32_t) * kXcd * static_cast<size_t>(vcap) * static_cast<size_t>(S), 256);
+                const size_t need = 256 + list_bytes + vis_bytes;
+                if (rec->bytes - rec->used < need) {
+                    rec->complete = 0;           // pool exhausted: the rest of the run is not recorded
+                } else {
+                    char *base = rec->pool + rec->used;
+                    rec->used += need;
+                    TrajChunk ch = {};
+                    ch.counts = reinterpret_cast<const uint32_t *>(base);
+                    ch.list = identity ? nullptr : reinterpret_cast<const int32_t *>(base + 256);
+                    ch.visits = reinterpret_cast<const uint32_t *>(base + 256 + list_bytes);
+                    ch.vcap = vcap;
+                    ch.cap = ws.cap;
+                    ch.steps = S;
+                    ch.transposed = (hist_t && binning_on) ? 1 : 0;
+                    hipError_t e1 = hipMemcpyAsync(base, ws.ctl->count[launch & 3], kXcd * sizeof(uint32_t),
+                                                   hipMemcpyDeviceToDevice, st);
+                    hipError_t e2 = identity ? hipSuccess
+                                             : hipMemcpy2DAsync(base + 256, sizeof(int32_t) * vcap, a.list_in,
+                                                                sizeof(int32_t) * ws.cap, sizeof(int32_t) * vcap, kXcd,
+                                                                hipMemcpyDeviceToDevice, st);
+                    if (e1 != hipSuccess || e2 != hipSuccess) { rc = set_error(SSRS_ERR_HIP, "trajectory record copy failed"); break; }
+                    rec->chunks.push_back(ch);
+                    a.visits = const_cast<uint32_t *>(ch.visits);
+                    a.visit_stride = static_cast<long long>(kXcd) * vcap;
+                    a.vcap = vcap;
+                    rec_counts = ch.counts;
+                }
+            }
             if (profile) {
                 hipEvent_t e;
                 if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); ev_prof.push_back(e); }
@@ -1973,11 +2121,11 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
                 hipEvent_t b0 = nullptr, b1 = nullptr;
                 if (profile && hipEventCreate(&b0) == hipSuccess) (void)hipEventRecord(b0, st);
                 if (hist_t)
-                    hipLaunchKernelGGL(k_bin_visits, dim3(S), dim3(kBinThreads), 0, st, ws.visits, ws.visit_stride,
-                                       ws.ctl, launch & 3, hist_t, p->cols, p->rows, ws.cap);
+                    hipLaunchKernelGGL(k_bin_visits, dim3(S), dim3(kBinThreads), 0, st, a.visits, a.visit_stride,
+                                       ws.ctl, launch & 3, hist_t, p->cols, p->rows, a.vcap);
                 else
-                    hipLaunchKernelGGL(k_bin_visits, dim3(S), dim3(kBinThreads), 0, st, ws.visits, ws.visit_stride,
-                                       ws.ctl, launch & 3, hist, p->rows, p->cols, ws.cap);
+                    hipLaunchKernelGGL(k_bin_visits, dim3(S), dim3(kBinThreads), 0, st, a.visits, a.visit_stride,
+                                       ws.ctl, launch & 3, hist, p->rows, p->cols, a.vcap);
                 if (profile && b0 && hipEventCreate(&b1) == hipSuccess) {
                     (void)hipEventRecord(b1, st);
                     ev_hist.push_back(b0);
@@ -1991,13 +2139,13 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
                 const double inv_cols = 1.0 / static_cast<double>(p->cols);
                 const uint32_t ucols = static_cast<uint32_t>(p->cols), ucell = static_cast<uint32_t>(ncell);
                 (void)hipMemsetAsync(ws.tile_count, 0, sizeof(uint32_t) * ntiles, st);
-                hipLaunchKernelGGL((k_tile_sort<false>), dim3(blocks, kStepSplit), dim3(kBlock), 0, st, ws.visits, ws.visit_stride, S,
-                                   ws.ctl, launch & 3, ucols, inv_cols, ucell, ws.cap, ntc, ntiles, ws.tile_count,
+                hipLaunchKernelGGL((k_tile_sort<false>), dim3(blocks, kStepSplit), dim3(kBlock), 0, st, a.visits, a.visit_stride, S,
+                                   ws.ctl, launch & 3, ucols, inv_cols, ucell, a.vcap, ntc, ntiles, ws.tile_count,
                                    ws.tile_cursor, ws.bucket);
                 hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(kTileThreads), 0, st, ws.tile_count, ntiles, ws.tile_start,
                                    ws.tile_cursor, ws.item_start);
-                hipLaunchKernelGGL((k_tile_sort<true>), dim3(blocks, kStepSplit), dim3(kBlock), 0, st, ws.visits, ws.visit_stride, S,
-                                   ws.ctl, launch & 3, ucols, inv_cols, ucell, ws.cap, ntc, ntiles, ws.tile_count,
+                hipLaunchKernelGGL((k_tile_sort<true>), dim3(blocks, kStepSplit), dim3(kBlock), 0, st, a.visits, a.visit_stride, S,
+                                   ws.ctl, launch & 3, ucols, inv_cols, ucell, a.vcap, ntc, ntiles, ws.tile_count,
                                    ws.tile_cursor, ws.bucket);
                 // at most S visits per slot of the launch, and one partly filled item per tile
                 const unsigned long long max_visits = static_cast<unsigned long long>(blocks) * kBlock * S;
@@ -2011,6 +2159,9 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
                     ev_hist.push_back(b1);
                 }
             }
+            if (rec_counts && hist && !binning_on && !tiles_on)      // recorded launch outside both binning paths
+                hipLaunchKernelGGL(k_count_visits, dim3(blocks), dim3(kBlock), 0, st, a.visits, a.vcap, S, rec_counts, hist,
+                                   static_cast<uint32_t>(ncell));
             if (hipGetLastError() != hipSuccess) { rc = set_error(SSRS_ERR_HIP, "stepper launch failed"); break; }
         }
         if (rc != SSRS_OK) break;
@@ -2055,6 +2206,8 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
                         a.vis_c = 1u;
                     } else {
                         binning_on = tiles_on = false;
+                        a.vis_r = static_cast<uint32_t>(p->cols);
+                        a.vis_c = 1u;
                         scattered = !never_scattered;      // no front any more: zero-mask variant
                     }
                 }
@@ -2118,5 +2271,76 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
     if (host_ctl.error)
         return set_error(SSRS_ERR_START, "ssrs_tracks_simulate: a start cell lies outside the %d x %d raster",
                          p->rows, p->cols);
+    return SSRS_OK;
+}
+
+extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updraft,
+                                    const float *potential, const double *table,
+                                    const int32_t *start_rc, int64_t ntracks, uint64_t seed,
+                                    uint64_t track_id_base, uint32_t *hist, int16_t *end_rc,
+                                    int32_t *lengths, int16_t *traj, const int64_t *traj_offsets,
+                                    void *workspace, size_t workspace_bytes,
+                                    SsrsTrackStats *stats, void *stream)
+{
+    return tracks_simulate_impl(p, updraft, potential, table, start_rc, ntracks, seed, track_id_base, hist, end_rc,
+                                lengths, traj, traj_offsets, workspace, workspace_bytes, stats, stream, nullptr);
+}
+
+extern "C" SsrsTrajRecorder *ssrs_traj_recorder_create(void *pool, size_t pool_bytes)
+{
+    if (!pool || (reinterpret_cast<uintptr_t>(pool) & 255u)) {
+        set_error(SSRS_ERR_INVALID, "ssrs_traj_recorder_create: pool must be non-NULL and 256-byte aligned");
+        return nullptr;
+    }
+    SsrsTrajRecorder *rec = new (std::nothrow) SsrsTrajRecorder();
+    if (!rec) { set_error(SSRS_ERR_INVALID, "ssrs_traj_recorder_create: out of host memory"); return nullptr; }
+    rec->pool = static_cast<char *>(pool);
+    rec->bytes = pool_bytes;
+    rec->used = 0;
+    rec->complete = 0;
+    rec->rows = rec->cols = 0;
+    rec->ntracks = -1;
+    return rec;
+}
+
+extern "C" void ssrs_traj_recorder_destroy(SsrsTrajRecorder *rec) { delete rec; }
+
+extern "C" int ssrs_traj_recorder_complete(const SsrsTrajRecorder *rec) { return rec ? rec->complete : 0; }
+
+extern "C" size_t ssrs_traj_recorder_used(const SsrsTrajRecorder *rec) { return rec ? rec->used : 0; }
+
+extern "C" int ssrs_tracks_simulate_rec(const SsrsTrackParams *p, const double *updraft,
+                                        const float *potential, const double *table,
+                                        const int32_t *start_rc, int64_t ntracks, uint64_t seed,
+                                        uint64_t track_id_base, uint32_t *hist, int16_t *end_rc,
+                                        int32_t *lengths, SsrsTrajRecorder *recorder,
+                                        void *workspace, size_t workspace_bytes,
+                                        SsrsTrackStats *stats, void *stream)
+{
+    SSRS_REQUIRE(recorder != nullptr, "ssrs_tracks_simulate_rec: recorder is NULL");
+    return tracks_simulate_impl(p, updraft, potential, table, start_rc, ntracks, seed, track_id_base, hist, end_rc,
+                                lengths, nullptr, nullptr, workspace, workspace_bytes, stats, stream, recorder);
+}
+
+extern "C" int ssrs_tracks_gather(const SsrsTrajRecorder *rec, const int32_t *start_rc, int64_t ntracks,
+                                  const int64_t *traj_offsets, int16_t *traj, void *cursor_ws,
+                                  size_t cursor_bytes, void *stream)
+{
+    SSRS_REQUIRE(rec != nullptr, "ssrs_tracks_gather: recorder is NULL");
+    SSRS_REQUIRE(rec->complete, "ssrs_tracks_gather: the record is incomplete (pool exhausted or no simulation yet)");
+    SSRS_REQUIRE(ntracks == rec->ntracks, "ssrs_tracks_gather: ntracks differs from the recorded simulation");
+    if (ntracks == 0) return SSRS_OK;
+    SSRS_REQUIRE(start_rc && traj_offsets && traj && cursor_ws, "ssrs_tracks_gather: NULL pointer");
+    SSRS_REQUIRE(cursor_bytes >= sizeof(uint32_t) * static_cast<size_t>(ntracks),
+                 "ssrs_tracks_gather: cursor scratch too small (4 bytes per track)");
+    hipStream_t st = as_stream(stream);
+    uint32_t *cursor = static_cast<uint32_t *>(cursor_ws);
+    const long long *off = reinterpret_cast<const long long *>(traj_offsets);
+    hipLaunchKernelGGL(k_gather_init, dim3(static_cast<unsigned>((ntracks + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                       start_rc, static_cast<long long>(ntracks), off, traj, cursor);
+    for (const TrajChunk &ch : rec->chunks)
+        hipLaunchKernelGGL(k_gather_chunk, dim3(kXcd * (ch.vcap / kBlock)), dim3(kBlock), 0, st, ch,
+                           static_cast<uint32_t>(rec->rows), static_cast<uint32_t>(rec->cols), off, traj, cursor);
+    SSRS_HIP_CHECK(hipGetLastError());
     return SSRS_OK;
 }

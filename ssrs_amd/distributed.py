@@ -42,24 +42,80 @@ def reduce_presence_sum(summary, group=None):
     return summary
 
 
-def reduce_histogram(hist, dst=0, group=None, all_ranks=False, async_op=False):
-    """In-place sum of the presence histogram over ranks.
+class HistogramOverflow(OverflowError):
+    """The sum of the ranks' per-cell maxima reaches 2^32: a 32-bit reduce could wrap."""
 
-    Counts are uint32 stored in an int32 tensor; two's-complement addition makes
-    the int32 sum bit-identical to the uint32 sum.  No-op without a process group.
+
+def _max_bound(hist, group):
+    """Sum over ranks of each rank's largest count (int64 scalar tensor): an upper bound
+    of the largest count of the reduced histogram."""
+    flat = hist.view(torch.int32).reshape(-1)
+    # uint32 stored in int32: the largest unsigned value is the min of the negatives if any
+    neg = flat.min()
+    local = torch.where(neg < 0, neg.to(torch.int64) + (1 << 32), flat.max().to(torch.int64)).reshape(1)
+    dist.all_reduce(local, op=dist.ReduceOp.SUM, group=group)
+    return local
+
+
+class _GuardedWork:
+    """Handle of an asynchronous guarded reduce: wait() orders the stream after the
+    collective and raises HistogramOverflow when the 32-bit sum may have wrapped."""
+
+    def __init__(self, work, bound_work, bound):
+        self._work, self._bound_work, self._bound = work, bound_work, bound
+
+    def wait(self):
+        self._work.wait()
+        if self._bound_work is not None:
+            self._bound_work.wait()
+            if int(self._bound.item()) >= (1 << 32):
+                raise HistogramOverflow('presence histogram: a cell may exceed 2^32 - 1 visits over '
+                                        'the ranks; reduce with async_op=False (64-bit sum)')
+        return True
+
+
+def reduce_histogram(hist, dst=0, group=None, all_ranks=False, async_op=False, guard=True):
+    """Sum of the presence histogram over ranks; returns the tensor that holds it.
+
+    Counts are uint32 stored in an int32 tensor; two's-complement addition makes the
+    int32 sum bit-identical to the uint32 sum as long as no cell passes 2^32 - 1.  With
+    `guard` (default) the ranks first add up their largest counts (one int64 scalar):
+    below 2^32 the sum cannot wrap and `hist` is reduced in place (120 MB at
+    5000 x 6000); otherwise the counts are widened to int64 and THAT tensor is reduced
+    and returned (presence.smooth_presence_counts accepts it).  Tracks that circle in a
+    pocket of the potential field until max_moves put ~1e9 visits into single cells
+    per 100k tracks, so eight such ranks would wrap a 32-bit sum.  No-op without a
+    process group.
 
     async_op=True returns a handle (or None when there is nothing to reduce) whose
     ``wait()`` orders the current stream after the collective: the reduce of one
     batch's histogram then runs on RCCL's stream under the next batch's stepper
-    launches (the caller must not touch `hist` before ``wait()``)."""
+    launches (the caller must not touch `hist` before ``wait()``).  The asynchronous
+    form always reduces 32-bit counts in place; its guard raises HistogramOverflow from
+    ``wait()`` instead of widening."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return None if async_op else hist
     flat = hist.view(torch.int32).reshape(-1)
-    if all_ranks:
-        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
-    else:
-        work = dist.reduce(flat, dst=dst, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
-    return work if async_op else hist
+
+    def run(t, **kw):
+        if all_ranks:
+            return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, **kw)
+        return dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM, group=group, **kw)
+
+    if async_op:
+        bound = bound_work = None
+        if guard:
+            neg = flat.min()
+            bound = torch.where(neg < 0, neg.to(torch.int64) + (1 << 32),
+                                flat.max().to(torch.int64)).reshape(1)
+            bound_work = dist.all_reduce(bound, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        return _GuardedWork(run(flat, async_op=True), bound_work, bound)
+    if guard and int(_max_bound(hist, group).item()) >= (1 << 32):
+        wide = flat.to(torch.int64) & 0xFFFFFFFF
+        run(wide)
+        return wide.reshape(hist.shape)
+    run(flat)
+    return hist
 
 
 def gather_track_summaries(lengths, ends, dst=0, group=None):

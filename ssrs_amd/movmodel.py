@@ -116,9 +116,21 @@ def build_transition_table(updraft, potential, ring=False):
 
 
 def ring_table_applies(memory_parameter, scaling_parameter, want_tracks, exact_only, steps_per_launch):
-    """The f32 ring table serves the reference's default movement model only."""
+    """The f32 ring table serves the reference's default movement model only.
+    `want_tracks` here means the two-pass trajectory form (the generic kernel writes the
+    points itself); recorded trajectories (simulate_tracks' default) keep the ring path."""
     return (int(memory_parameter) == 1 and float(scaling_parameter) == 1.0 and not want_tracks
             and not exact_only and int(steps_per_launch) % 2 == 0)
+
+
+def default_record_pool_bytes(n, rows, cols):
+    """Pool for recorded trajectories: a launch of S = 512 steps needs 4 B x S x live slots,
+    so a batch that crosses the raster in ~rows steps needs about n x rows x 4 B x 1.5;
+    bounded by a quarter of the free HBM (the pool is only scratch: when it runs out the
+    run falls back to the two-pass form)."""
+    free, _ = torch.cuda.mem_get_info()
+    want = int(n) * 4 * max(int(rows), int(cols)) * 3 + (64 << 20)
+    return int(max(1 << 20, min(want, free // 4))) // 256 * 256
 
 
 class TrackBatch:
@@ -146,7 +158,7 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
                     seed=0, track_id_base=0, table=None, use_table=None, hist=None,
                     want_hist=True, want_tracks=False, steps_per_launch=0, profile=False,
                     exact_only=False, schedule=True, binning=True, ring=None, scattered=None,
-                    max_moves=None):
+                    max_moves=None, record=True, record_pool_bytes=None):
     """generate_simulated_tracks for a whole batch (movmodel.py:264-318 under
     simulator.py:360-369) + presence histogram (movmodel.py:410-419).
 
@@ -155,8 +167,15 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
     build_transition_table) or use_table=True selects the one-fetch-per-step
     path; default: table when it pays (many steps per cell).  A float32
     `table` is the ring table (build_transition_table(..., ring=True)); when the
-    table is built here, ring=None picks it whenever it applies (memory 1, nu 1,
-    no trajectories).  `hist` (int32/uint32 CUDA tensor) is accumulated into when given.
+    table is built here, ring=None picks it whenever it applies (memory 1, nu 1).
+    `hist` (int32/uint32 CUDA tensor) is accumulated into when given.
+
+    want_tracks: trajectories (TrackBatch.tracks()).  record=True (default) keeps every
+    launch's visited cells in a device pool and assembles the trajectories afterwards
+    (ssrs_tracks_simulate_rec + ssrs_tracks_gather): ONE simulation pass on whichever
+    stepper path applies.  record=False, or a pool that ran out, takes the two-pass
+    form: lengths first, then the same counter-based streams again with the generic
+    kernel writing each point at its final offset.
     """
     rows, cols = int(grid_shape[0]), int(grid_shape[1])
     dev = device()
@@ -170,6 +189,7 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
             raise ValueError(f'{name} shape {tuple(f.shape)} != grid_shape {(rows, cols)}')
     if pot is not None and upd is None:
         raise ValueError('potential_field needs updraft_field')
+    two_pass = bool(want_tracks) and not record
     if table is None and upd is not None:
         if use_table is None:
             # building costs ~1 window evaluation per cell; pays once the batch
@@ -177,14 +197,14 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
             use_table = n * rows >= 4 * rows * cols
         if use_table:
             if ring is None:
-                ring = ring_table_applies(memory_parameter, scaling_parameter, want_tracks,
+                ring = ring_table_applies(memory_parameter, scaling_parameter, two_pass,
                                           exact_only, steps_per_launch)
             table = build_transition_table(upd, pot, ring=bool(ring))
     is_ring = table is not None and table.dtype == torch.float32
-    if is_ring and not ring_table_applies(memory_parameter, scaling_parameter, want_tracks,
+    if is_ring and not ring_table_applies(memory_parameter, scaling_parameter, two_pass,
                                           exact_only, steps_per_launch):
         raise ValueError('the ring table needs memory_parameter 1, scaling_parameter 1, no '
-                         'trajectory output, exact_only=False and an even steps_per_launch')
+                         'two-pass trajectory output, exact_only=False and an even steps_per_launch')
     p = make_track_params((rows, cols), move_dirn, memory_parameter, scaling_parameter,
                           steps_per_launch, profile, exact_only, schedule, binning, ring=is_ring,
                           scattered=scattered)
@@ -213,22 +233,63 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
             C.c_size_t(ws_bytes), C.byref(stats), stream_ptr()))
 
     traj = offsets = None
-    if want_tracks:
-        # pass 1: lengths only; pass 2 replays the same counter-based streams
-        # and writes every point at its final offset (no per-track cap).
-        run(None, None, None)
+    recorded = simulated = False
+    if want_tracks and record and n > 0:
+        # one pass: every launch's visits stay in the pool, the gather assembles them
+        pool_bytes = int(record_pool_bytes) if record_pool_bytes is not None else \
+            default_record_pool_bytes(n, rows, cols)
+        pool = torch.empty(max(256, pool_bytes // 256 * 256), dtype=torch.uint8, device=dev)
+        rec = nat.lib().ssrs_traj_recorder_create(nat.ptr(pool), C.c_size_t(pool.numel()))
+        if not rec:
+            nat.check(nat.SSRS_ERR_INVALID)
+        try:
+            nat.check(nat.lib().ssrs_tracks_simulate_rec(
+                C.byref(p), nat.ptr(upd), nat.ptr(pot), nat.ptr(table), nat.ptr(st),
+                C.c_int64(n), C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF),
+                C.c_uint64(int(track_id_base)), nat.ptr(hist), nat.ptr(ends),
+                nat.ptr(lengths), C.c_void_p(rec), nat.ptr(ws), C.c_size_t(ws_bytes),
+                C.byref(stats), stream_ptr()))
+            if nat.lib().ssrs_traj_recorder_complete(C.c_void_p(rec)):
+                offsets = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+                torch.cumsum(lengths, 0, out=offsets[1:])
+                total = int(offsets[-1].item())
+                traj = torch.empty((total, 2), dtype=torch.int16, device=dev)
+                cursor = torch.empty(n, dtype=torch.int32, device=dev)
+                nat.check(nat.lib().ssrs_tracks_gather(
+                    C.c_void_p(rec), nat.ptr(st), C.c_int64(n), nat.ptr(offsets), nat.ptr(traj),
+                    nat.ptr(cursor), C.c_size_t(4 * n), stream_ptr()))
+                torch.cuda.current_stream().synchronize()      # the pool dies with this scope
+                recorded = True
+            simulated = True                  # lengths, end cells and the histogram are final
+        finally:
+            nat.lib().ssrs_traj_recorder_destroy(C.c_void_p(rec))
+            del pool
+        if not recorded and is_ring:
+            # the two-pass form runs the generic kernel, which reads the f64 table
+            table = build_transition_table(upd, pot, ring=False)
+            p = make_track_params((rows, cols), move_dirn, memory_parameter, scaling_parameter,
+                                  steps_per_launch, profile, exact_only, schedule, binning, ring=False,
+                                  scattered=scattered)
+            if max_moves is not None:
+                p.max_moves = int(max_moves)
+    if want_tracks and not recorded:
+        # pass 1: lengths only (done already when a recorded run ran out of pool); pass 2
+        # replays the same counter-based streams and writes every point at its final
+        # offset (no per-track cap).
+        if not simulated:
+            run(None, None, None)
         offsets = torch.zeros(n + 1, dtype=torch.int64, device=dev)
         torch.cumsum(lengths, 0, out=offsets[1:])
         total = int(offsets[-1].item())
         traj = torch.empty((total, 2), dtype=torch.int16, device=dev)
-        run(hist, traj, offsets)
-    else:
+        run(None if simulated else hist, traj, offsets)
+    elif not want_tracks:
         run(hist, None, None)
     return TrackBatch(lengths, ends, hist, traj, offsets,
                       dict(total_steps=int(stats.total_steps), launches=int(stats.launches),
                            kernel_ms=float(stats.kernel_ms), wall_ms=float(stats.wall_ms),
                            hist_ms=float(stats.hist_ms), window_launches=int(stats.window_launches),
-                           tile_launches=int(stats.tile_launches)))
+                           tile_launches=int(stats.tile_launches), recorded=bool(recorded)))
 
 
 def generate_simulated_tracks(move_dirn, start_location, grid_shape, memory_parameter=1,

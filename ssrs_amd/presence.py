@@ -35,16 +35,20 @@ def compute_presence_counts(tracks, gridshape):
 
 
 def smooth_presence_counts(count_mat, radius):
-    """Disk smoothing of a count matrix (movmodel.py:431-439) -> f32."""
+    """Disk smoothing of a count matrix (movmodel.py:431-439) -> f32.  int64 counts (the
+    widened sum of distributed.reduce_histogram) take the 64-bit kernel, everything else is
+    read as uint32-in-int32."""
     cnt = to_dev(count_mat)
-    if cnt.dtype not in (torch.int32,):
+    wide = cnt.dtype == torch.int64
+    if not wide and cnt.dtype != torch.int32:
         cnt = cnt.to(torch.int32)
     rows, cols = int(cnt.shape[0]), int(cnt.shape[1])
     krad = int(radius)
     out = torch.empty((rows, cols), dtype=torch.float32, device=cnt.device)
     nbytes = nat.lib().ssrs_presence_workspace_bytes(rows, cols, krad)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=cnt.device)
-    nat.check(nat.lib().ssrs_presence_smooth(
+    fn = nat.lib().ssrs_presence_smooth_u64 if wide else nat.lib().ssrs_presence_smooth
+    nat.check(fn(
         nat.ptr(cnt), krad, nat.ptr(out), rows, cols, nat.ptr(ws), C.c_size_t(nbytes),
         stream_ptr()))
     return like_input(out, count_mat)

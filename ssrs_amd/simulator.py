@@ -113,8 +113,9 @@ class Simulator(Config):
             print(f'Uniform mode: Wind dirn = {self.uniform_winddirn} deg(cw)')
             self.case_ids = [self._get_uniform_id()]
             self.compute_orographic_updraft_uniform()
-        for case_id in self.case_ids:
+        for case_id in self._cases_written_here():
             self.compute_thermal_updrafts(case_id)
+        self._barrier()
 
         fig_aspect = self.region_width_km[0] / self.region_width_km[1]
         self.fig_size = (self.fig_height * fig_aspect, self.fig_height)
@@ -202,7 +203,7 @@ class Simulator(Config):
         kernel (DEM -> orograph); with slope/aspect layers injected, the
         elementwise kernel on those layers."""
         print('Computing orographic updrafts..')
-        if self.case_ids[0] not in self.my_case_ids():
+        if self.case_ids[0] not in self._cases_written_here():
             return
         if 'Slope' in self._terrain or 'Aspect' in self._terrain:
             orograph = layers.compute_orographic_updraft(
@@ -223,7 +224,7 @@ class Simulator(Config):
         batch = 8
         # DEM-only terrain and wind on one regular lattice: the fused kernel (DEM read once
         # per batch, no per-cell wind rasters, no slope / aspect rasters)
-        mine = set(self.my_case_ids())
+        mine = set(self._cases_written_here())
         wind = [it for it in self._wind if it['case_id'] in mine]
         lattice = len(wind) > 0 and all('x_km' in it for it in wind) and \
             not ('Slope' in self._terrain or 'Aspect' in self._terrain) and \
@@ -276,9 +277,14 @@ class Simulator(Config):
             from .thermals import compute_thermals
             print('Computing thermal updrafts...', flush=True)
             aspect = self.get_terrain_aspect()
+            # the reference draws every case / realisation from one advancing numpy stream
+            # (layers.py:188-214), so all fields differ; here each gets its own counter-based
+            # key from (sim_seed, position of the case, realisation)
+            base = (self.sim_seed if self.sim_seed >= 0 else
+                    int.from_bytes(os.urandom(4), 'little'))
+            case_no = self.case_ids.index(case_id) if case_id in self.case_ids else 0
             for real_id in range(self.thermals_realization_count):
-                seed = (self.sim_seed if self.sim_seed >= 0 else
-                        int.from_bytes(os.urandom(4), 'little')) + 7919 * (real_id + 1)
+                seed = base + 7919 * (real_id + 1) + 104729 * case_no
                 thermals = compute_thermals(aspect, 2.0, seed=seed)
                 fname = self._get_thermal_fname(case_id, real_id, self.mode_data_dir)
                 np.save(f'{fname}.npy', np.asarray(thermals, dtype=np.float32))
@@ -358,8 +364,54 @@ class Simulator(Config):
             return int(self.sim_seed) + int(real_id)
         return int.from_bytes(os.urandom(7), 'little')
 
+    # device-resident forms of load_updrafts / get_directional_potential: the public methods
+    # keep the reference's numpy-in / numpy-out contract, the stepper takes these
+    def _load_updrafts_dev(self, case_id):
+        fname = self._get_orograph_fname(case_id, self.mode_data_dir)
+        orograph = to_dev(np.load(f'{fname}.npy'), torch.float32)
+        fields = [orograph]
+        for real_id in range(int(self.thermals_realization_count)):
+            fname = self._get_thermal_fname(case_id, real_id, self.mode_data_dir)
+            fields.append(orograph + to_dev(np.load(f'{fname}.npy'), torch.float32))
+        return [layers.get_above_threshold_speed(f, self.updraft_threshold) for f in fields]
+
+    def _potential_dev(self, updraft, case_id, real_id):
+        """get_directional_potential on device tensors: the cached .npy when valid, else
+        the GPU solve (written to the cache by the rank that owns the case)."""
+        fname = self._get_potential_fname(case_id, real_id, self.mode_data_dir)
+        id_str = self._get_id_string(case_id, real_id)
+        sharded = self._shards_tracks()
+        if sharded and self._rank() != 0:
+            self._barrier()                       # rank 0 solves (or finds the cache) and saves
+            return to_dev(np.load(f'{fname}.npy'), torch.float32)
+        try:
+            potential = np.load(f'{fname}.npy')
+            if potential.shape != self.gridsize:
+                raise FileNotFoundError
+            if (self.sim_seed < 0) & (real_id != 0):
+                raise FileNotFoundError
+            print(f'{id_str}: Found saved potential')
+            pot = to_dev(potential, torch.float32)
+        except FileNotFoundError as _:
+            start_time = time.time()
+            print(f'{id_str}: Computing potential..', end="", flush=True)
+            pot = potential_mod.solve_potential(updraft, self.track_direction)
+            torch.cuda.current_stream().synchronize()
+            print(f'took {_elapsed(start_time)}', flush=True)
+            np.save(f'{fname}.npy', pot.cpu().numpy())
+        if bool(torch.isnan(pot).any()):
+            print('NANs found in potential!')
+        if sharded:
+            self._barrier()
+        return pot
+
     def simulate_tracks(self):
-        """simulator.py:332-386."""
+        """simulator.py:332-386.  With a torch.distributed process group (one process per
+        GPU) the work is sharded like SURVEY 8(e): wind cases over the ranks when there are
+        at least as many cases as ranks (seasonal mode), otherwise the TRACKS of every case
+        over the ranks by contiguous global id ranges (uniform / snapshot mode): each rank
+        steps its share against its own replica of the rasters, the presence histograms are
+        summed over the ranks and rank 0 writes the case's <id>_tracks.pkl."""
         print(f'Movement model = {self.movement_model}')
         print(f'Updraft threshold = {self.updraft_threshold} m/s')
         print(f'Movement direction = {self.track_direction} deg (cw)')
@@ -369,23 +421,29 @@ class Simulator(Config):
         starts = np.stack([starting_rows, starting_cols], 1).astype(np.int32)
         use_table = {'auto': None, 'table': True, 'direct': False}[self.stepper_path]
         self.last_stats = {}
+        sharded = self._shards_tracks()
+        lo, hi = 0, len(starts)
+        if sharded:
+            from .distributed import shard_range
+            lo, hi = shard_range(len(starts), self._rank(), self._world())
+        my_starts = to_dev(starts[lo:hi], torch.int32)
+
         # (case, realisation) items are independent: like the reference's loop
         # they are prepared in order on this thread (file cache, reseeding), then
         # stepped concurrently, one HIP stream per worker thread (seasonal mode
         # has many small batches that cannot fill the GPU one at a time).
         def prepare():
             for case_id in self.my_case_ids():
-                updrafts = self.load_updrafts(case_id, apply_threshold=True)
+                fluid = self.movement_model == 'fluidflow'
+                if self.movement_model not in ('fluidflow', 'drw'):
+                    raise ValueError(f'unknown movement_model {self.movement_model!r}')
+                updrafts = self._load_updrafts_dev(case_id) if fluid else \
+                    [None] * (1 + int(self.thermals_realization_count))
                 for real_id, updraft in enumerate(updrafts):
                     if self.sim_seed > 0:
                         np.random.seed(self.sim_seed + real_id)
-                    if self.movement_model == 'fluidflow':
-                        potential = self.get_directional_potential(updraft, case_id, real_id)
-                        fields = (updraft, potential)
-                    elif self.movement_model == 'drw':
-                        fields = (None, None)
-                    else:
-                        raise ValueError(f'unknown movement_model {self.movement_model!r}')
+                    fields = (updraft, self._potential_dev(updraft, case_id, real_id)) if fluid \
+                        else (None, None)
                     yield (case_id, real_id, fields, self._stream_seed(real_id))
 
         def run(item):
@@ -394,22 +452,25 @@ class Simulator(Config):
             start_time = time.time()
             with torch.cuda.stream(torch.cuda.Stream()):
                 batch = movmodel.simulate_tracks(
-                    self.track_direction, starts, self.gridsize, self.track_dirn_restrict,
-                    self.track_stochastic_nu, fields[0], fields[1], seed=seed,
+                    self.track_direction, my_starts, self.gridsize, self.track_dirn_restrict,
+                    self.track_stochastic_nu, fields[0], fields[1], seed=seed, track_id_base=lo,
                     use_table=use_table, want_tracks=bool(self.save_tracks),
                     steps_per_launch=self.steps_per_launch)
                 tracks = batch.tracks() if self.save_tracks else None
                 torch.cuda.current_stream().synchronize()
-            print(f'{id_str}: Simulating {self.track_count} tracks..took {_elapsed(start_time)}',
+            print(f'{id_str}: Simulating {hi - lo} tracks..took {_elapsed(start_time)}',
                   flush=True)
             if self.save_tracks:
                 fname = self._get_tracks_fname(case_id, real_id, self.mode_data_dir)
-                with open(f'{fname}.pkl', "wb") as fobj:
-                    pickle.dump(tracks, fobj)
+                self._write_tracks(fname, tracks, sharded)
+            if sharded:
+                from .distributed import reduce_histogram
+                batch.hist = reduce_histogram(batch.hist, all_ranks=True)
             return (case_id, real_id), batch
 
         nitems = max(1, len(self.my_case_ids())) * (1 + int(self.thermals_realization_count))
-        workers = max(1, min(nitems, int(self.max_cores), 8))
+        # collectives of the track-sharded form must be issued in the same order on every rank
+        workers = 1 if sharded else max(1, min(nitems, int(self.max_cores), 8))
 
         def collect(results):
             for key, batch in results:
@@ -419,7 +480,7 @@ class Simulator(Config):
         if workers == 1:
             collect(run(it) for it in prepare())
         else:
-            # bounded pipeline: at most `workers` prepared items (host rasters) alive
+            # bounded pipeline: at most `workers` prepared items (device rasters) alive
             from concurrent.futures import ThreadPoolExecutor, wait, FIRST_COMPLETED
             with ThreadPoolExecutor(workers) as pool:
                 pending = set()
@@ -429,6 +490,27 @@ class Simulator(Config):
                         done, pending = wait(pending, return_when=FIRST_COMPLETED)
                         collect(f.result() for f in done)
                 collect(f.result() for f in pending)
+
+    def _write_tracks(self, fname, tracks, sharded):
+        """<id>_tracks.pkl (simulator.py:382-385).  Track-sharded runs: every rank writes
+        its share next to it, rank 0 concatenates the shares in rank order (= global track
+        id order) into the one file of the contract and removes them."""
+        if not sharded:
+            with open(f'{fname}.pkl', "wb") as fobj:
+                pickle.dump(tracks, fobj)
+            return
+        with open(f'{fname}.pkl.part{self._rank()}', "wb") as fobj:
+            pickle.dump(tracks, fobj)
+        self._barrier()
+        if self._rank() == 0:
+            merged = []
+            for r in range(self._world()):
+                with open(f'{fname}.pkl.part{r}', 'rb') as fobj:
+                    merged.extend(pickle.load(fobj))
+                os.remove(f'{fname}.pkl.part{r}')
+            with open(f'{fname}.pkl', "wb") as fobj:
+                pickle.dump(merged, fobj)
+        self._barrier()
 
     # ------------------------------------------------------------- presence
     def _counts_for(self, case_id, real_id):
@@ -457,27 +539,59 @@ class Simulator(Config):
                 presence.normalise_add(prprob, case_prob)       # prprob /= amax; case += prprob
             presence.normalise_add(case_prob, summary)          # case /= amax; summary += case
             self.case_presence[case_id] = case_prob
-        from .distributed import reduce_presence_sum
-        reduce_presence_sum(summary)                            # cases of the other ranks
+        if not self._shards_tracks():
+            from .distributed import reduce_presence_sum
+            reduce_presence_sum(summary)                        # cases of the other ranks
         out = presence.normalise_to_f32(summary).cpu().numpy()  # summary /= amax -> f32
         if self._rank() == 0:
             np.save(os.path.join(self.mode_data_dir, 'summary_presence.npy'), out)
+        self._barrier()
         return out
 
     # ---------------------------------------------------------- multi-GPU
     @staticmethod
-    def _rank():
+    def _dist_on():
         import torch.distributed as dist
-        return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        return dist.is_available() and dist.is_initialized()
+
+    @classmethod
+    def _rank(cls):
+        import torch.distributed as dist
+        return dist.get_rank() if cls._dist_on() else 0
+
+    @classmethod
+    def _world(cls):
+        import torch.distributed as dist
+        return dist.get_world_size() if cls._dist_on() else 1
+
+    @classmethod
+    def _barrier(cls):
+        import torch.distributed as dist
+        if cls._dist_on() and dist.get_world_size() > 1:
+            dist.barrier()
+
+    def _shards_tracks(self):
+        """Fewer wind cases than ranks (uniform / snapshot mode: one case): the tracks of
+        each case are sharded over the ranks instead of the cases (BASELINE configs[2])."""
+        return self._world() > 1 and len(self.case_ids) < self._world()
 
     def my_case_ids(self):
         """Cases this rank simulates: with a torch.distributed process group (one process
-        per GPU) the wind cases are sharded contiguously over the ranks: every
-        rank computes, saves and simulates only its own cases, and compute_presence_map
-        sums the per-case maps over the ranks.  (A single uniform-mode case lands on rank 0;
-        sharding ONE case's tracks over GPUs is what bench.py / distributed.shard_range do.)"""
+        per GPU) the wind cases are sharded contiguously over the ranks and
+        compute_presence_map sums the per-case maps over the ranks; with fewer cases than
+        ranks every rank takes every case and a share of its tracks (simulate_tracks)."""
+        if self._shards_tracks():
+            return list(self.case_ids)
         from .distributed import shard_cases
         return shard_cases(self.case_ids)
+
+    def _cases_written_here(self):
+        """Cases whose rasters (orograph, thermals) this rank computes and saves: its own
+        cases, or -- track-sharded -- all of them on rank 0 (the other ranks read the
+        files after the barrier that ends the constructor)."""
+        if self._shards_tracks():
+            return list(self.case_ids) if self._rank() == 0 else []
+        return self.my_case_ids()
 
     def plot_presence_map(self, plot_turbs=True, radius: float = 1000., show=False,
                           minval=0.1, plot_all: bool = False) -> None:

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Golden-vector generator: runs the REFERENCE hot-path modules in the build
 container and stores inputs + outputs as small .npz fixtures (SURVEY.md 8(c),
-G1..G9).  Fixtures are data; the reference's source never enters the repo and
+G1..G12).  Fixtures are data; the reference's source never enters the repo and
 never travels to the GPU box.
 
 How the reference is loaded: /root/reference/ssrs/{movmodel,layers}.py are
@@ -16,7 +16,7 @@ algorithm with the uniform made explicit (cumsum -> /last -> searchsorted
 'right'); `check_choice_equivalence()` proves the replacement reproduces the
 legacy-MT trajectories bit for bit before any Philox-driven golden is made.
 
-Usage:  python tests/golden/generate_golden.py [--skip-c1]
+Usage:  python tests/golden/generate_golden.py [--skip-c1] [--skip-10m]
 While generating, every vector is also compared with oracle/ssrs_oracle.py and
 the script aborts on any mismatch.
 """
@@ -396,15 +396,271 @@ def g8_c1(ntracks=1000, procs=8):
          first_tracks=np.concatenate(tracks[:8]), first_lengths=lens[:8])
 
 
+# ------------------------------------------------------------ G10: the 10 m regime
+_G10 = {}
+
+
+def _g10_worker(t):
+    uni = TrackUniforms(_G10['seed'], t)
+    return ref_track(0., _G10['starts'][t], _G10['shape'], 1, 1., _G10['upd'], _G10['pot'], uni)
+
+
+def shuffle_f32(a):
+    """f32 raster -> byte planes (all byte 0, all byte 1, ...): the sign/exponent planes
+    deflate well, so the .npz stays small.  tests/conftest.py:unshuffle_f32 undoes it."""
+    a = np.ascontiguousarray(a, dtype='<f4')
+    return np.ascontiguousarray(a.view(np.uint8).reshape(-1, 4).T)
+
+
+G10_WINDOW = (1000, 1200, 1000, 1200)      # row0, col0, rows, cols of the C2 DEM
+
+
+def g10_10m(ntracks=256, procs=8):
+    """The regime of BASELINE configs[1..4]: a 1000 x 1200 window of the 5000 x 6000 @10 m
+    DEM of SURVEY 8(d) (rows 1000.., cols 1200..: a lee slope with 1/4-1/3 live cells in the
+    south, a windward slope with > 80 % live cells in the north; at 10 m the per-cell noise
+    term dominates the slopes, so both phases are speckled).  Reference potential (assemble +
+    SuperLU, movmodel.py:59-128) and reference tracks (:264-318) under the Philox injection."""
+    r0, c0, rows, cols = G10_WINDOW
+    print(f'G10 10 m regime: {rows}x{cols} window at ({r0}, {c0}) of the C2 DEM, {ntracks} tracks, '
+          'seed 30 (reference, slow)')
+    res = 10.
+    shape = (rows, cols)
+    z = synthetic_dem((5000, 6000), res)[r0:r0 + rows, c0:c0 + cols].copy()
+    slope = ly.compute_slope_degrees(z, res)
+    aspect = ly.compute_aspect_degrees(z, res)
+    oro = ly.compute_orographic_updraft(10. * np.ones(shape), 270. * np.ones(shape), slope, aspect)
+    oro32 = oro.astype(np.float32)
+    upd = ly.get_above_threshold_speed(oro32, 0.75)
+    assert upd.dtype == np.float64
+    model = mm.MovModel(0., shape)
+    bn, be = model.get_boundary_nodes()
+    ri, ci, fa = model.assemble_sparse_linear_system()
+    print('   reference potential solve ...', flush=True)
+    pot = model.solve_sparse_linear_system(upd, bn, be, ri, ci, fa)
+    del ri, ci, fa
+    opot = orc.solve_potential(upd, 0.)
+    np.testing.assert_allclose(opot, pot, rtol=2e-6, atol=1e-4)
+    # local extrema of the f32 field away from the Dirichlet rows: the exact solution is
+    # discrete-harmonic (no interior extrema); plateaus over live clusters are allowed
+    p = pot.astype(np.float64)
+    inner = p[1:-1, 1:-1]
+    nb = np.stack([p[1 + dr:rows - 1 + dr, 1 + dc:cols - 1 + dc]
+                   for dr in (-1, 0, 1) for dc in (-1, 0, 1) if (dr, dc) != (0, 0)])
+    strict_min = int((inner[None] < nb).all(0)[1:-1].sum())
+    strict_max = int((inner[None] > nb).all(0)[1:-1].sum())
+    width_km = (cols * res / 1000., rows * res / 1000.)
+    np.random.seed(30)
+    srows, scols = mm.get_starting_indices(ntracks, (1., width_km[0] - 1., 0.1, 0.3), 'random',
+                                           width_km, res)
+    _G10.update(seed=30, starts=list(zip(srows, scols)), shape=shape, upd=upd, pot=pot)
+    print('   reference tracks ...', flush=True)
+    with mp.get_context('fork').Pool(procs) as pool:
+        tracks = pool.map(_g10_worker, range(ntracks), chunksize=4)
+    lens = np.array([len(t) for t in tracks])
+    ends = np.array([t[-1] for t in tracks])
+    mine = c_oracle_tracks(starts=np.stack([srows, scols], 1), shape=shape, upd=upd, pot=pot)
+    assert np.array_equal(mine['lengths'], lens), 'C oracle lengths differ from the reference'
+    for a, b in zip(mine['tracks'], tracks):
+        assert np.array_equal(a, b), 'C oracle trajectory differs from the reference'
+    sha = hashlib.sha256()
+    for t in tracks:
+        sha.update(np.ascontiguousarray(t, dtype='<i2').tobytes())
+    hist = np.zeros(shape, dtype=np.int32)
+    for t in tracks:
+        np.add.at(hist, (t[:, 0].astype(int), t[:, 1].astype(int)), 1)
+    hr, hc = np.nonzero(hist)
+    steps = lens - 1
+    print(f'   steps/track mean {steps.mean():.0f} median {np.median(steps):.0f} max {steps.max()} '
+          f'(max_moves {rows // 2 * (cols // 2)}); dead cells {np.mean(upd == 0):.3f}; '
+          f'strict interior minima {strict_min}, maxima {strict_max}', flush=True)
+    save('g10_10m.npz', shape=np.array(shape), res=res, window=np.array(G10_WINDOW),
+         orograph_f32_planes=shuffle_f32(oro32), potential_planes=shuffle_f32(pot),
+         start_rows=srows, start_cols=scols, seed=30, lengths=lens, ends=ends,
+         traj_sha256=np.array(sha.hexdigest()),
+         hist_rows=hr.astype(np.int16), hist_cols=hc.astype(np.int16),
+         hist_vals=hist[hr, hc].astype(np.int32),
+         first_tracks=np.concatenate(tracks[:4]), first_lengths=lens[:4],
+         dead_fraction=np.mean(upd == 0), strict_minima=strict_min, strict_maxima=strict_max,
+         max_moves=rows // 2 * (cols // 2))
+
+
+def c_oracle_tracks(starts, shape, upd, pot):
+    from oracle import c_oracle
+    return c_oracle.simulate_tracks(0., starts, shape, 1, 1., upd, pot, seed=30,
+                                    want_traj=True, want_hist=False)
+
+
+# ------------------------------------------- G11: tracks that wander until max_moves
+def g11_wander(ntracks=64, procs=8):
+    """The whole 60 x 50 km domain of SURVEY 8(d) at 50 m (1000 x 1200 cells, the largest
+    size SuperLU factorises here in about a minute): with the reference's own potential
+    about half of the reference's tracks never leave the raster -- they reach a basin of
+    the potential field whose outlet the f32 field does not resolve, circle there and stop
+    at max_moves = 300 000 (movmodel.py:277,285).  Pins that regime (the one the 10 m
+    configs live in: tools/probe_traps.py) to the reference: potential, lengths, end cells
+    and the sha256 over every point of the 64 tracks."""
+    rows, cols, res = 1000, 1200, 50.
+    print(f'G11 wandering regime: {rows}x{cols} @50 m, {ntracks} tracks, seed 30 (reference, slow)')
+    shape = (rows, cols)
+    z, slope, aspect, oro, oro32, upd = small_case(rows, cols, res)
+    assert upd.dtype == np.float64
+    model = mm.MovModel(0., shape)
+    bn, be = model.get_boundary_nodes()
+    ri, ci, fa = model.assemble_sparse_linear_system()
+    print('   reference potential solve ...', flush=True)
+    pot = model.solve_sparse_linear_system(upd, bn, be, ri, ci, fa)
+    del ri, ci, fa
+    opot = orc.solve_potential(upd, 0.)
+    np.testing.assert_allclose(opot, pot, rtol=2e-6, atol=1e-4)
+    np.random.seed(30)
+    srows, scols = mm.get_starting_indices(ntracks, (5, 55, 1, 2), 'random', (60., 50.), res)
+    starts = np.stack([srows, scols], 1)
+    # the C port first (seconds): how many tracks run into max_moves
+    mine = c_oracle_tracks(starts=starts, shape=shape, upd=upd, pot=pot)
+    max_moves = rows // 2 * (cols // 2)
+    print(f'   C oracle: {np.mean(mine["lengths"] > max_moves):.2f} of the tracks stop at max_moves; '
+          'reference tracks ...', flush=True)
+    _G10.update(seed=30, starts=list(zip(srows, scols)), shape=shape, upd=upd, pot=pot)
+    with mp.get_context('fork').Pool(procs) as pool:
+        tracks = pool.map(_g10_worker, range(ntracks), chunksize=1)
+    lens = np.array([len(t) for t in tracks])
+    ends = np.array([t[-1] for t in tracks])
+    assert np.array_equal(mine['lengths'], lens), 'C oracle lengths differ from the reference'
+    for a, b in zip(mine['tracks'], tracks):
+        assert np.array_equal(a, b), 'C oracle trajectory differs from the reference'
+    sha = hashlib.sha256()
+    for t in tracks:
+        sha.update(np.ascontiguousarray(t, dtype='<i2').tobytes())
+    hist = np.zeros(shape, dtype=np.int32)
+    for t in tracks:
+        np.add.at(hist, (t[:, 0].astype(int), t[:, 1].astype(int)), 1)
+    hr, hc = np.nonzero(hist)
+    steps = lens - 1
+    print(f'   steps/track median {np.median(steps):.0f} max {steps.max()} (max_moves {max_moves}); '
+          f'at max_moves {np.mean(steps >= max_moves):.3f}; busiest cell {hist.max()} visits', flush=True)
+    save('g11_wander.npz', shape=np.array(shape), res=res,
+         orograph_f32_planes=shuffle_f32(oro32), potential_planes=shuffle_f32(pot),
+         start_rows=srows, start_cols=scols, seed=30, lengths=lens, ends=ends,
+         traj_sha256=np.array(sha.hexdigest()),
+         hist_rows=hr.astype(np.int16), hist_cols=hc.astype(np.int16),
+         hist_vals=hist[hr, hc].astype(np.int32), max_moves=max_moves,
+         dead_fraction=np.mean(upd == 0))
+
+
+# ----------------------------- G12: exact solutions of the reference's potential systems
+def reference_system(conductivity, move_dirn):
+    """The linear system of MovModel.solve_sparse_linear_system (movmodel.py:98-120) as
+    matrices, entry for entry in the reference's arithmetic (on NumPy >= 2 the 1e-08 of a
+    dead pair divided by the f32 `fac` is an f32 value): (A csc, b, inner nodes, boundary
+    nodes, boundary energy).  g12 checks that SuperLU on it returns the reference's field
+    bit for bit before using it."""
+    import scipy.sparse as ss
+    nrow, ncol = conductivity.shape
+    n = nrow * ncol
+    model = mm.MovModel(move_dirn, (nrow, ncol))
+    bnodes, benergy = model.get_boundary_nodes()
+    ri, ci, facs = model.assemble_sparse_linear_system()
+    r = ri.astype(np.int64)
+    c = ci.astype(np.int64)
+    ca = conductivity[r % nrow, r // nrow]
+    cb = conductivity[c % nrow, c // nrow]
+    live = (ca != 0) & (cb != 0)
+    with np.errstate(divide='ignore'):
+        vals = np.where(live, (2. / (1. / ca + 1. / cb)) / facs,
+                        (np.float32(1e-08) / facs).astype(np.float64) if
+                        isinstance(1e-08 / facs[0], np.float32) else 1e-08 / facs)
+    g_csr = ss.coo_matrix((vals, (r, c)), shape=(n, n)).tocsr()
+    g_csr.data = g_csr.data / np.repeat(np.add.reduceat(g_csr.data, g_csr.indptr[:-1]),
+                                        np.diff(g_csr.indptr))
+    inodes = np.setdiff1d(np.arange(0, n), bnodes, assume_unique=True)
+    g_inner_csc = g_csr[inodes, :].tocoo().tocsc()
+    b_vec = g_inner_csc[:, bnodes].dot(benergy)
+    a_matrix = ss.eye(np.size(inodes)).tocsc() - g_inner_csc[:, inodes]
+    return a_matrix, b_vec, inodes, bnodes, benergy
+
+
+def exact_potential(conductivity, move_dirn, ref_field=None, sweeps=4):
+    """The exact solution of that system: SuperLU + iterative refinement with the residual
+    accumulated in x87 extended precision (converges: condition ~1e10 x 2^-64 << 1)."""
+    import scipy.sparse.linalg as ssl
+    nrow, ncol = conductivity.shape
+    a_mat, b_vec, inodes, bnodes, benergy = reference_system(conductivity, move_dirn)
+    lu = ssl.splu(a_mat)
+    x0 = lu.solve(b_vec)
+
+    def field(xi):
+        e = np.empty(nrow * ncol)
+        e[inodes] = xi
+        e[bnodes] = benergy
+        return e.reshape(ncol, nrow).T
+
+    if ref_field is not None:
+        same = np.mean(field(x0).astype(np.float32) == ref_field)
+        print(f'      SuperLU on the restated system reproduces {same:.6f} of the reference field bit for bit')
+        assert same == 1.0
+    a_csr = a_mat.tocsr()
+    a_csr.sort_indices()
+    dl = a_csr.data.astype(np.longdouble)
+    bl = b_vec.astype(np.longdouble)
+    x = x0.astype(np.longdouble)
+    for it in range(sweeps):
+        res = bl - np.add.reduceat(dl * x[a_csr.indices], a_csr.indptr[:-1])
+        dx = lu.solve(res.astype(np.float64))
+        x = x + dx.astype(np.longdouble)
+        print(f'      refinement {it}: max |dx| {np.abs(dx).max():.3e}', flush=True)
+    assert np.abs(dx).max() < 1e-6
+    return field(x.astype(np.float64))
+
+
+def g12_exact():
+    """How good is the reference's own field?  For C1 (G8), the 10 m window (G10) and the
+    50 m domain (G11): the exact solution of the reference's system, f32-rounded, on a strided
+    sample -- the yardstick for ssrs_potential_solve, since SuperLU's field is itself several
+    f32 ulp off at these condition numbers."""
+    print('G12 exact potentials (SuperLU + extended-precision refinement)')
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from conftest import unshuffle_f32
+    out = {}
+    for tag, fname, stride in (('c1', 'g8_c1.npz', 2), ('g10', 'g10_10m.npz', 3), ('g11', 'g11_wander.npz', 3)):
+        g = np.load(os.path.join(HERE, fname))
+        if 'orograph_f32' in g:
+            oro32, ref = g['orograph_f32'], g['potential']
+        else:
+            shape = tuple(int(v) for v in g['shape'])
+            oro32 = unshuffle_f32(g['orograph_f32_planes'], shape)
+            ref = unshuffle_f32(g['potential_planes'], shape)
+        upd = ly.get_above_threshold_speed(oro32, 0.75)
+        print(f'   {tag}: {upd.shape}', flush=True)
+        exact = exact_potential(upd, 0., ref_field=ref)
+        d = np.abs(ref.astype(np.float64) - exact)
+        e32 = exact.astype(np.float32)
+        ulp = np.abs(e32.view(np.int32).astype(np.int64) - ref.view(np.int32))
+        print(f'      reference field vs exact: max {d.max():.3e}, mean {d.mean():.3e}; '
+              f'{np.mean(ulp == 0):.3f} of its cells are the correctly rounded value, max {ulp.max()} ulp')
+        out[f'{tag}_stride'] = stride
+        out[f'{tag}_exact_f32'] = e32[::stride, ::stride].copy()
+        out[f'{tag}_ref_max_err'] = d.max()
+        out[f'{tag}_ref_mean_err'] = d.mean()
+        out[f'{tag}_ref_max_ulp'] = ulp.max()
+        out[f'{tag}_ref_exact_share'] = np.mean(ulp == 0)
+    save('g12_exact_potential.npz', **out)
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--skip-c1', action='store_true')
+    ap.add_argument('--skip-10m', action='store_true')
     ap.add_argument('--only', default='')
     args = ap.parse_args()
     todo = [g1_constants, g2_raster, g3_threshold, g4_starts, g5_potential,
             g6_move_probs, g7_tracks, g9_presence]
     if not args.skip_c1:
         todo.append(g8_c1)
+    if not args.skip_10m:
+        todo.append(g10_10m)
+        todo.append(g11_wander)
+        todo.append(g12_exact)
     for fn in todo:
         if args.only and args.only not in fn.__name__:
             continue

@@ -72,6 +72,22 @@ def _worker(rank, world, port, out_dir):
         assert w is not None
         w.wait()
     assert all(torch.equal(b, h2) for b in bufs)
+    # wrap guard: 3e9 visits in one cell on every rank cannot be summed in 32 bits
+    big = np.zeros((3, 4), dtype=np.uint32)
+    big[1, 2] = 3_000_000_000
+    big[0, 0] = 7 + rank
+    hb = torch.from_numpy(big.view(np.int32).copy())
+    wide = reduce_histogram(hb, all_ranks=True)
+    assert wide.dtype == torch.int64 and wide.shape == hb.shape
+    assert int(wide[1, 2]) == 3_000_000_000 * world and int(wide[0, 0]) == sum(7 + r for r in range(world))
+    from ssrs_amd.distributed import HistogramOverflow
+    hb = torch.from_numpy(big.view(np.int32).copy())
+    work = reduce_histogram(hb, all_ranks=True, async_op=True)
+    try:
+        work.wait()
+        raise AssertionError('the asynchronous guard did not fire')
+    except HistogramOverflow:
+        pass
     dist.barrier()
     dist.destroy_process_group()
 

@@ -1,0 +1,57 @@
+"""BASELINE configs[2] / configs[4] through the product API on ONE GPU: two fresh processes
+(gloo group, both on cuda:0) run Simulator.simulate_tracks + compute_presence_map; the files
+rank 0 leaves behind must equal the single-process run's bit for bit -- tracks sharded over the
+ranks in uniform / snapshot mode (one case), cases sharded in seasonal mode
+(/root/reference/ssrs/simulator.py:347-369 maps tracks over a pool; :200-215 loops over cases)."""
+import glob
+import os
+import pickle
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run(world, out_dir, mode):
+    port = str(_free_port())
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, 'mp_simulator_worker.py'), str(r), str(world),
+                               port, out_dir, mode], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(world)]
+    outs = [p.communicate(timeout=600)[0].decode('utf-8', 'replace') for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f'rank {r} failed:\n{o[-3000:]}'
+    return os.path.join(out_dir, f'{mode}_w{world}', 'data', mode)
+
+
+@pytest.mark.parametrize('mode', ['uniform', 'snapshot', 'seasonal'])
+def test_two_ranks_equal_one_rank(gpu, tmp_path, mode):
+    one = _run(1, str(tmp_path), mode)
+    two = _run(2, str(tmp_path), mode)
+    names = sorted(os.path.basename(f) for f in glob.glob(os.path.join(one, '*')))
+    assert names == sorted(os.path.basename(f) for f in glob.glob(os.path.join(two, '*'))), \
+        'the two-rank run left a different set of files (stray .part files?)'
+    assert any(n.endswith('_tracks.pkl') for n in names) and 'summary_presence.npy' in names
+    for n in names:
+        a, b = os.path.join(one, n), os.path.join(two, n)
+        if n.endswith('.npy'):
+            assert np.array_equal(np.load(a), np.load(b)), n
+        elif n.endswith('.pkl'):
+            with open(a, 'rb') as fa, open(b, 'rb') as fb:
+                ta, tb = pickle.load(fa), pickle.load(fb)
+            assert len(ta) == len(tb)
+            for x, y in zip(ta, tb):
+                assert np.array_equal(x, y), n

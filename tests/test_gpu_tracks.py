@@ -600,3 +600,63 @@ def test_wandering_batches_move_from_the_window_to_tile_buckets(gpu, dirn):
         assert np.array_equal(lens, ref['lengths']), kw
         assert np.array_equal(hist, ref['hist']), kw
         assert res.stats['window_launches'] > 0 and res.stats['tile_launches'] > 0, res.stats
+
+
+# ------------------------------------------------------------ recorded trajectories
+# want_tracks=True records every launch's visits and gathers them afterwards (one
+# simulation pass, any stepper path); record=False is the two-pass form.
+
+@pytest.mark.parametrize('dirn,n,kw', [
+    (0., 9000, dict(use_table=True, ring=True)),            # row window binning, ring kernel
+    (0., 9000, dict(use_table=True, ring=False)),           # f64 three-candidate kernel
+    (90., 9000, dict(use_table=True, ring=True)),           # transposed visit keys
+    (45., 9000, dict(use_table=True, ring=True)),           # tile buckets
+    (200., 700, dict(use_table=True, ring=True)),           # small batch: per-visit atomics
+    (0., 700, dict(use_table=False)),                       # window gathers, generic kernel
+    (30., 9000, dict(use_table=True, memory=3)),            # generic table kernel
+    (0., 9000, dict(use_table=True, ring=True, schedule=False)),   # identity first list
+    (0., 9000, dict(use_table=True, ring=True, steps_per_launch=34)),
+])
+def test_recorded_trajectories_equal_the_oracle(gpu, dirn, n, kw):
+    from ssrs_amd import movmodel
+    from oracle import c_oracle
+    rows, cols = 260, 330
+    upd, _ = _random_field_case(rows, cols, 41)
+    th = np.deg2rad(dirn)
+    rr = np.arange(rows)[:, None]; cc = np.arange(cols)[None, :]
+    along = rr * np.cos(th) + cc * np.sin(th)
+    rng = np.random.default_rng(8)
+    pot = (1000. * (1 - (along - along.min()) / (along.max() - along.min())) +
+           rng.normal(0, 0.05, (rows, cols))).astype(np.float32)
+    starts = np.stack([rng.integers(2, rows - 2, n), rng.integers(2, cols - 2, n)], 1)
+    kw = dict(kw)
+    mem = kw.pop('memory', 1)
+    ref = c_oracle.simulate_tracks(dirn, starts, (rows, cols), mem, 1., upd, pot, seed=17, track_id_base=3)
+    res = movmodel.simulate_tracks(dirn, starts, (rows, cols), mem, 1., upd, pot, seed=17, track_id_base=3,
+                                   want_tracks=True, **kw)
+    assert res.stats['recorded'], 'the trajectory pool was exhausted'
+    assert np.array_equal(res.lengths.cpu().numpy(), ref['lengths'])
+    assert np.array_equal(res.ends.cpu().numpy(), ref['ends'])
+    assert np.array_equal(res.hist.cpu().numpy().view(np.uint32), ref['hist'])
+    assert np.array_equal(res.traj.cpu().numpy(), np.concatenate(ref['tracks']))
+
+
+def test_record_pool_overflow_falls_back_to_two_passes(gpu):
+    from ssrs_amd import movmodel
+    from oracle import c_oracle
+    rows, cols = 120, 150
+    upd, pot = _random_field_case(rows, cols, 5)
+    rng = np.random.default_rng(9)
+    starts = np.stack([rng.integers(2, 20, 3000), rng.integers(0, cols, 3000)], 1)
+    ref = c_oracle.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=4)
+    hist0 = torch.full((rows, cols), 5, dtype=torch.int32, device='cuda')     # accumulated into
+    for pool, expect in ((1 << 20, False), (None, True)):
+        hist = hist0.clone()
+        res = movmodel.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=4, use_table=True,
+                                       want_tracks=True, record_pool_bytes=pool, steps_per_launch=64, hist=hist)
+        assert res.stats['recorded'] == expect
+        assert np.array_equal(res.traj.cpu().numpy(), np.concatenate(ref['tracks']))
+        assert np.array_equal((res.hist - 5).cpu().numpy().view(np.uint32), ref['hist'])
+    two = movmodel.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=4, use_table=True,
+                                   want_tracks=True, record=False)
+    assert not two.stats['recorded'] and torch.equal(two.traj, res.traj)

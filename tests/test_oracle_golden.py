@@ -192,3 +192,56 @@ def test_cell_weights_match_window(golden):
         got = c_oracle.cell_weights(g['updraft'], g['potential'], r, c)
         want = np.array([max(v, 0.) for k, v in enumerate(w) if k != 4])
         assert np.array_equal(got, want)
+
+
+def test_g10_10m_regime_c_oracle(g10):
+    """G10: 1000 x 1200 window of the 10 m DEM, reference potential (assemble + SuperLU) and
+    256 reference tracks: the C port reproduces every trajectory (sha256), the numpy
+    restatement the first four."""
+    import hashlib
+    shape = g10['shape']
+    upd = orc.get_above_threshold_speed(g10['orograph_f32'], 0.75)
+    assert abs(float(np.mean(upd == 0)) - float(g10['dead_fraction'])) < 1e-12
+    starts = np.stack([g10['start_rows'], g10['start_cols']], 1)
+    res = c_oracle.simulate_tracks(0., starts, shape, 1, 1., upd, g10['potential'],
+                                   seed=int(g10['seed']), want_traj=True, want_hist=True)
+    assert np.array_equal(res['lengths'], g10['lengths'])
+    assert np.array_equal(res['ends'], g10['ends'])
+    sha = hashlib.sha256()
+    for t in res['tracks']:
+        sha.update(np.ascontiguousarray(t, dtype='<i2').tobytes())
+    assert sha.hexdigest() == str(g10['traj_sha256'])
+    assert np.array_equal(res['hist'].astype(np.int32), g10['hist'])
+    # the reference's tracks cross this raster in ~1 step per row: nothing wanders
+    steps = g10['lengths'] - 1
+    assert steps.max() < 2 * shape[0] and steps.max() < int(g10['max_moves']) // 100
+    off = 0
+    for t in range(2):
+        n = int(g10['first_lengths'][t])
+        tr = orc.generate_simulated_tracks(0., (int(starts[t, 0]), int(starts[t, 1])), shape, 1, 1.,
+                                           upd, g10['potential'], uniform=TrackUniforms(int(g10['seed']), t))
+        assert np.array_equal(tr, g10['first_tracks'][off:off + n])
+        off += n
+
+
+def test_g11_wandering_tracks_c_oracle(g11):
+    """G11: the 60 x 50 km domain at 50 m with the reference's own potential: 30 of the
+    reference's 64 tracks never leave the raster and stop at max_moves = 300 000
+    (movmodel.py:277,285).  The C port reproduces all of them point for point."""
+    import hashlib
+    shape = g11['shape']
+    upd = orc.get_above_threshold_speed(g11['orograph_f32'], 0.75)
+    starts = np.stack([g11['start_rows'], g11['start_cols']], 1)
+    res = c_oracle.simulate_tracks(0., starts, shape, 1, 1., upd, g11['potential'],
+                                   seed=int(g11['seed']), want_traj=True, want_hist=True)
+    assert np.array_equal(res['lengths'], g11['lengths'])
+    assert np.array_equal(res['ends'], g11['ends'])
+    sha = hashlib.sha256()
+    for t in res['tracks']:
+        sha.update(np.ascontiguousarray(t, dtype='<i2').tobytes())
+    assert sha.hexdigest() == str(g11['traj_sha256'])
+    assert np.array_equal(res['hist'].astype(np.int32), g11['hist'])
+    steps = g11['lengths'] - 1
+    mm = int(g11['max_moves'])
+    assert mm == 300000 and 0.4 < np.mean(steps >= mm) < 0.55      # the wandering IS the reference's
+    assert np.median(steps[steps < mm]) < 3 * shape[0]             # the others cross in ~1 step per row

@@ -11,7 +11,7 @@ dem = torch.from_numpy(synthetic_dem(shape, 10.)).cuda()
 _, upd = layers.updraft_from_dem(dem, 10., 10., 270., threshold=0.75)
 with warnings.catch_warnings():
     warnings.simplefilter('ignore')
-    pot, st = solve_potential(upd, 0., rel_tol=1e-8, max_iterations=1500, return_stats=True)
+    pot, st = solve_potential(upd, 0., max_iterations=3000, return_stats=True)   # library default rel_tol
 np.random.seed(30)
 r, c = movmodel.get_starting_indices(100000, (5, 55, 1, 2), 'random', (60., 50.), 10.)
 starts = np.stack([r, c], 1)[:1500]

@@ -11,7 +11,7 @@ dem = torch.from_numpy(synthetic_dem(shape, 10.)).cuda()
 _, upd = layers.updraft_from_dem(dem, 10., 10., 270., threshold=0.75)
 with warnings.catch_warnings():
     warnings.simplefilter('ignore')
-    pot, st = solve_potential(upd, 0., rel_tol=1e-9, max_iterations=1500, return_stats=True)
+    pot, st = solve_potential(upd, 0., max_iterations=3000, return_stats=True)
 print('solve', st['iterations'], flush=True)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 np.random.seed(30)

@@ -11,6 +11,6 @@ _, upd = layers.updraft_from_dem(dem, 10., 10., 270., threshold=0.75)
 torch.cuda.synchronize(); t = time.time()
 with warnings.catch_warnings():
     warnings.simplefilter('ignore')
-    pot, st = solve_potential(upd, 0., rel_tol=float(os.environ.get('SOLVE_TOL', '1e-8')), max_iterations=2000, return_stats=True)
+    pot, st = solve_potential(upd, 0., rel_tol=float(os.environ.get('SOLVE_TOL', '1e-15')), max_iterations=2000, return_stats=True)
 torch.cuda.synchronize()
 print(shape, st, 'wall', round(time.time() - t, 2), 's', 'peak GB', round(torch.cuda.max_memory_allocated() / 1e9, 1), flush=True)
