@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libssrs_hip.so')
+LIB_PATH = os.environ.get('SSRS_HIP_LIB') or os.path.join(_HERE, 'libssrs_hip.so')   # (override: timing probes only)
 
 SSRS_F32, SSRS_F64 = 0, 1
 SSRS_OK, SSRS_ERR_INVALID, SSRS_ERR_HIP, SSRS_ERR_START = 0, -1, -2, -3

@@ -46,5 +46,24 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_probe(defines, tag):
+    """Timing-probe variant of the library (tools/probe_chain.py): tracks.hip recompiled with
+    -D<defines>, linked with the product's other objects into libssrs_probe_<tag>.so."""
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    build()
+    out = os.path.join(PKG, f'libssrs_probe_{tag}.so')
+    obj = os.path.join(HERE, f'tracks_probe_{tag}.o')
+    subprocess.check_call([hipcc] + FLAGS + [f'-D{d}' for d in defines] +
+                          ['-c', os.path.join(HERE, 'tracks.hip'), '-o', obj])
+    objs = [os.path.join(HERE, os.path.splitext(s)[0] + '.o') for s in SOURCES if s != 'tracks.hip'] + [obj]
+    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs)
+    return out
+
+
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv, verbose=True))
+    if '--probe' in sys.argv:
+        for tag, defs in (('nophilox', ['SSRS_PROBE_NO_PHILOX']), ('nogather', ['SSRS_PROBE_NO_GATHER']),
+                          ('neither', ['SSRS_PROBE_NO_PHILOX', 'SSRS_PROBE_NO_GATHER'])):
+            print(build_probe(defs, tag))
+    else:
+        print(build(force='--force' in sys.argv, verbose=True))

@@ -193,8 +193,16 @@ __host__ __device__ constexpr size_t ring_mask_offset(int rows, int cols)
 // ------------------------------------------------------------------- uniform
 // rocRAND Philox4x32-10: key = seed, counter = (blk, track); one 4-word block
 // serves two steps.  The engine is built and dropped in registers (stateless).
+// SSRS_PROBE_* are timing probes of tools/probe_chain.py (built into libssrs_probe_*.so by
+// csrc/build.py --probe; results are wrong on purpose and the product build never defines them):
+// NO_PHILOX replaces the generator by two multiplies, NO_GATHER the table gather by constants.
 __device__ __forceinline__ uint4 philox_block(uint64_t seed, uint64_t track, uint64_t blk)
 {
+#ifdef SSRS_PROBE_NO_PHILOX
+    const uint32_t h = static_cast<uint32_t>(blk) * 0x9E3779B9u ^ static_cast<uint32_t>(track) * 0x85EBCA6Bu ^
+                       static_cast<uint32_t>(seed);
+    return make_uint4(h * 0xC2B2AE35u, h ^ 0x27D4EB2Fu, (h >> 3) * 0x165667B1u, h + 0x9E3779B9u);
+#endif
     rocrand_state_philox4x32_10 st;
     rocrand_init(seed, track, blk * 4ull, &st);
     return rocrand4(&st);
@@ -1039,7 +1047,12 @@ __global__ __launch_bounds__(kBlock) void k_step_lean(const StepArgs a)
                 if (tri == 7u && rc != 8u) x = RingTriple{-0.0f, -0.0f, -0.0f};
                 else x = *reinterpret_cast<const RingTriple *>(src);
             } else {
+#ifdef SSRS_PROBE_NO_GATHER
+                (void)src;
+                x = RingTriple{1.0f, 2.0f + static_cast<float>(er & 1), 1.5f};
+#else
                 x = *reinterpret_cast<const RingTriple *>(src);
+#endif
             }
         } else {
             cand = candidates_of(dirs & 0xFu);

@@ -549,12 +549,14 @@ def g11_wander(ntracks=64, procs=8):
 
 
 # ----------------------------- G12: exact solutions of the reference's potential systems
-def reference_system(conductivity, move_dirn):
+def reference_system(conductivity, move_dirn, numpy2=True):
     """The linear system of MovModel.solve_sparse_linear_system (movmodel.py:98-120) as
-    matrices, entry for entry in the reference's arithmetic (on NumPy >= 2 the 1e-08 of a
-    dead pair divided by the f32 `fac` is an f32 value): (A csc, b, inner nodes, boundary
-    nodes, boundary energy).  g12 checks that SuperLU on it returns the reference's field
-    bit for bit before using it."""
+    matrices, entry for entry in the reference's arithmetic: (A csc, b, inner nodes, boundary
+    nodes, boundary energy).  `numpy2`: `harmonic_mean(...) / fac` divides the python float
+    1e-08 of a dead pair by an np.float32 -- an f32 value under NumPy >= 2 (NEP 50, the NumPy
+    of this container, so the goldens carry it), an f64 value under the NumPy < 1.24 the
+    reference was written for (it uses np.int).  g12 checks that SuperLU on the numpy2 form
+    returns the golden field bit for bit."""
     import scipy.sparse as ss
     nrow, ncol = conductivity.shape
     n = nrow * ncol
@@ -567,9 +569,8 @@ def reference_system(conductivity, move_dirn):
     cb = conductivity[c % nrow, c // nrow]
     live = (ca != 0) & (cb != 0)
     with np.errstate(divide='ignore'):
-        vals = np.where(live, (2. / (1. / ca + 1. / cb)) / facs,
-                        (np.float32(1e-08) / facs).astype(np.float64) if
-                        isinstance(1e-08 / facs[0], np.float32) else 1e-08 / facs)
+        dead = (np.float32(1e-08) / facs).astype(np.float64) if numpy2 else 1e-08 / facs.astype(np.float64)
+        vals = np.where(live, (2. / (1. / ca + 1. / cb)) / facs, dead)
     g_csr = ss.coo_matrix((vals, (r, c)), shape=(n, n)).tocsr()
     g_csr.data = g_csr.data / np.repeat(np.add.reduceat(g_csr.data, g_csr.indptr[:-1]),
                                         np.diff(g_csr.indptr))
@@ -580,12 +581,12 @@ def reference_system(conductivity, move_dirn):
     return a_matrix, b_vec, inodes, bnodes, benergy
 
 
-def exact_potential(conductivity, move_dirn, ref_field=None, sweeps=4):
+def exact_potential(conductivity, move_dirn, ref_field=None, sweeps=4, numpy2=True):
     """The exact solution of that system: SuperLU + iterative refinement with the residual
     accumulated in x87 extended precision (converges: condition ~1e10 x 2^-64 << 1)."""
     import scipy.sparse.linalg as ssl
     nrow, ncol = conductivity.shape
-    a_mat, b_vec, inodes, bnodes, benergy = reference_system(conductivity, move_dirn)
+    a_mat, b_vec, inodes, bnodes, benergy = reference_system(conductivity, move_dirn, numpy2)
     lu = ssl.splu(a_mat)
     x0 = lu.solve(b_vec)
 
@@ -632,12 +633,19 @@ def g12_exact():
             ref = unshuffle_f32(g['potential_planes'], shape)
         upd = ly.get_above_threshold_speed(oro32, 0.75)
         print(f'   {tag}: {upd.shape}', flush=True)
-        exact = exact_potential(upd, 0., ref_field=ref)
+        exact = exact_potential(upd, 0., ref_field=ref)           # the system the goldens were made with
         d = np.abs(ref.astype(np.float64) - exact)
         e32 = exact.astype(np.float32)
         ulp = np.abs(e32.view(np.int32).astype(np.int64) - ref.view(np.int32))
         print(f'      reference field vs exact: max {d.max():.3e}, mean {d.mean():.3e}; '
               f'{np.mean(ulp == 0):.3f} of its cells are the correctly rounded value, max {ulp.max()} ulp')
+        # the same system with f64 dead entries (NumPy < 1.24 semantics; what ssrs_potential_solve
+        # implements): its exact solution is the yardstick stored here
+        exact1 = exact_potential(upd, 0., numpy2=False)
+        print(f'      f32 vs f64 dead-pair entries move the exact solution by up to '
+              f'{np.abs(exact1 - exact).max():.3e}')
+        out[f'{tag}_numpy2_shift'] = np.abs(exact1 - exact).max()
+        e32 = exact1.astype(np.float32)
         out[f'{tag}_stride'] = stride
         out[f'{tag}_exact_f32'] = e32[::stride, ::stride].copy()
         out[f'{tag}_ref_max_err'] = d.max()
