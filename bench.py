@@ -55,7 +55,8 @@ def parse():
     ap.add_argument('--no-binning', action='store_true', help='per-step global atomics for the histogram')
     ap.add_argument('--no-schedule', action='store_true', help='disable the coherent schedule')
     ap.add_argument('--exact-only', action='store_true', help='disable the fast decision path')
-    ap.add_argument('--f64-table', action='store_true', help='8 x f64 transition table instead of the f32 ring table')
+    ap.add_argument('--f64-table', action='store_true', help='8 x f64 transition table instead of the threshold table')
+    ap.add_argument('--ring-table', action='store_true', help='f32 ring table (round 1 stepper) instead of the threshold table')
     ap.add_argument('--dem-noise', type=float, default=1.5,
                     help='sigma of the per-cell DEM noise in metres (SURVEY 8(d) prescribes 1.5 at every resolution)')
     return ap.parse_args()
@@ -113,6 +114,14 @@ def cpu_baseline(args, gridsize, dem, pot, starts, seed, steps_per_track):
     }, run, m
 
 
+def build_table(args, movmodel, upd, pot):
+    if args.f64_table or args.exact_only:
+        return movmodel.build_transition_table(upd, pot)
+    if args.ring_table:
+        return movmodel.build_transition_table(upd, pot, ring=True)
+    return movmodel.build_transition_table(upd, pot, thr=True, move_dirn=0.0)
+
+
 def chain_probe(args, movmodel, layers, dem, pot, starts_h, gridsize, res, seed):
     """What bounds the stepper: one step of a track is a chain of dependent instructions
     (Philox -> decision -> next address -> 12-byte gather -> ...).  A batch of 16 384 tracks is
@@ -120,7 +129,7 @@ def chain_probe(args, movmodel, layers, dem, pot, starts_h, gridsize, res, seed)
     full batch (1.5 waves per SIMD) cannot run a launch faster than S x that latency."""
     import torch
     _, upd = layers.updraft_from_dem(dem, res, 10.0, 270.0, threshold=0.75)
-    table = movmodel.build_transition_table(upd, pot, ring=not (args.f64_table or args.exact_only))
+    table = build_table(args, movmodel, upd, pot)
     n = 16384
     sub = torch.from_numpy(starts_h[:n]).to(dem.device)
     best = None
@@ -162,7 +171,7 @@ def solved_leg(args, movmodel, layers, dem, starts_h, gridsize, res, seed):
     sub = torch.from_numpy(starts_h[:n]).to(dem.device)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    table = movmodel.build_transition_table(upd, pot, ring=True)
+    table = build_table(args, movmodel, upd, pot)
     o = movmodel.simulate_tracks(0.0, sub, gridsize, 1, 1.0, upd, pot, seed=seed, table=table, profile=True)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -265,7 +274,7 @@ def main():
         ev[0].record()
         oro, upd = layers.updraft_from_dem(dem, res, 10.0, 270.0, threshold=0.75)
         ev[1].record()
-        table = None if args.direct else movmodel.build_transition_table(upd, pot, ring=not (args.f64_table or args.exact_only))
+        table = None if args.direct else build_table(args, movmodel, upd, pot)
         ev[2].record()
         out = movmodel.simulate_tracks(0.0, starts, gridsize, 1, 1.0, upd, pot, seed=seed,
                                        track_id_base=lo, table=table, use_table=not args.direct,
@@ -331,7 +340,9 @@ def main():
     assert int(hist.sum().item()) == total_steps_all // K + n_total, 'histogram checksum failed'
     kernel_s = acc['step_kernel_ms'] / 1e3
     # bytes the chosen data path really requests per step (read + 4 B visit / histogram update)
-    moved_bytes = 76 if args.direct else (92 if args.exact_only else (28 if args.f64_table else 16))
+    # (window gathers 18 x 4 + 4; f64 table row 64 + 24 + 4; f64 three candidates 24 + 4; ring triple
+    # 12 + 4; threshold pair 8 + 4)
+    moved_bytes = 76 if args.direct else (92 if args.exact_only else (28 if args.f64_table else (16 if args.ring_table else 12)))
     achieved = acc['steps'] * STEP_BYTES / kernel_s / 1e9 if kernel_s > 0 else 0.0
     moved_gbps = acc['steps'] * moved_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0
     raster_s = acc['raster_ms'] / 1e3 / K
@@ -357,7 +368,9 @@ def main():
                               if world > 1 else ''),
             'stepper_path': ('direct 3x3 gathers' if args.direct else
                              ('f64 transition table' if (args.f64_table or args.exact_only)
-                              else 'f32 ring table, exact fallback on the raw windows')),
+                              else ('f32 ring table, exact fallback on the raw windows' if args.ring_table else
+                                    'f32 threshold table (two decision thresholds per cell and last move), '
+                                    'exact fallback on the raw windows'))),
             'potential': pot_label,
         },
         'steps_per_s': total_steps_all / elapsed,
@@ -373,7 +386,7 @@ def main():
         },
         'roofline': {
             'kernel': ('k_step_tracks' if (args.direct or args.f64_table or args.exact_only)
-                       else 'k_step_lean<ring>') + ' (K2 stepper, rank 0)',
+                       else ('k_step_lean<ring>' if args.ring_table else 'k_step_thr')) + ' (K2 stepper, rank 0)',
             # what bounds it: the dependent chain of one step (see dependent_chain below and
             # profiles/r02_stepper_chain.md), not HBM: the kernel moves 16 B per step
             'bound': 'latency',
@@ -397,7 +410,7 @@ def main():
     # HBM bytes per launch from the PMC passes (profiles/, separate --pmc runs): only quoted when
     # THIS run is the configuration those passes profiled
     pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-    default_variant = (world == 1 and args.potential == 'ramp' and not (args.direct or args.f64_table or args.exact_only
+    default_variant = (world == 1 and args.potential == 'ramp' and not (args.direct or args.f64_table or args.exact_only or args.ring_table
                        or args.no_binning or args.no_schedule) and args.tracks == 100_000 and res == 10.0
                        and args.steps_per_launch in (0, 512) and args.dem_noise == 1.5)
     if os.path.exists(pmc) and default_variant:

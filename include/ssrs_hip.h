@@ -171,6 +171,11 @@ typedef struct SsrsTrackParams {
                                       per-step window to tile buckets and only then to this
                                       variant; small ones directly.  Results are identical */
 #define SSRS_TRACKS_NO_SCATTERED 64 /* never switch to that variant (A/B) */
+#define SSRS_TRACKS_THR_TABLE 128   /* `table` is the threshold table of ssrs_transition_thr_build (one aligned
+                                      8-byte gather and two comparisons per step); needs updraft (+ potential
+                                      if the table was built with it) for the exact decision of near-ties,
+                                      memory_parameter 1, scaling_parameter 1, traj NULL, even steps_per_launch,
+                                      and params->prior equal to the prior the table was built with */
 #define SSRS_TRACKS_EXACT_ONLY 2 /* disable the guarded division-free decision
                                    (A/B switch; results are identical) */
 
@@ -210,6 +215,19 @@ int ssrs_transition_table_build(const double *updraft, const float *potential,
 size_t ssrs_transition_ring_bytes(int rows, int cols);
 int ssrs_transition_ring_build(const double *updraft, const float *potential, float *ring,
                                int rows, int cols, void *stream);
+
+/* The decision thresholds themselves (SSRS_TRACKS_THR_TABLE): for every cell and every last move
+ * rc (ring position 0..7) the two f32 numbers 2^24 a / (a + b + c), 2^24 (a + b) / (a + b + c), with
+ * a, b, c the three admissible weights of movmodel.py:292-309 in ascending neighbour index -- the
+ * boundaries np.random.choice's inverse-cdf pick compares the uniform with.  A row whose weights are
+ * all zero carries the masked prior's thresholds (movmodel.py:234-238); boundary cells, poisoned rows
+ * and rows where the unmasked prior decides are NaN-coded flags.  Eight planes (one per last move)
+ * of 8-byte entries at a power-of-two stride, ssrs_transition_thr_bytes(rows, cols) bytes in all,
+ * 64-byte aligned; the table belongs to one heading (`prior` [host], 9 doubles =
+ * SsrsTrackParams.prior).  rows * cols <= 2^26. */
+size_t ssrs_transition_thr_bytes(int rows, int cols);
+int ssrs_transition_thr_build(const double *updraft, const float *potential, const double *prior,
+                              float *thr, int rows, int cols, void *stream);
 
 /* Bytes of device scratch ssrs_tracks_simulate needs for `ntracks` (about 4.2 KB per
  * track: two buffers of 512 steps x 4 B for the launch's visited cells, in slot and in

@@ -19,6 +19,7 @@ SSRS_TRACKS_NO_BINNING = 8
 SSRS_TRACKS_RING_TABLE = 16
 SSRS_TRACKS_SCATTERED = 32
 SSRS_TRACKS_NO_SCATTERED = 64
+SSRS_TRACKS_THR_TABLE = 128
 SSRS_SOLVE_NO_AMG = 1
 
 EXPORTS = (
@@ -28,6 +29,7 @@ EXPORTS = (
     'ssrs_wind_from_lattice', 'ssrs_thermal_seeds', 'ssrs_blur_workspace_bytes',
     'ssrs_gaussian_blur', 'ssrs_track_params_init', 'ssrs_transition_table_build',
     'ssrs_transition_ring_bytes', 'ssrs_transition_ring_build',
+    'ssrs_transition_thr_bytes', 'ssrs_transition_thr_build',
     'ssrs_tracks_workspace_bytes', 'ssrs_tracks_workspace_bytes_ex', 'ssrs_tracks_simulate', 'ssrs_uniform_selftest',
     'ssrs_traj_recorder_create', 'ssrs_traj_recorder_destroy', 'ssrs_traj_recorder_complete',
     'ssrs_traj_recorder_used', 'ssrs_tracks_simulate_rec', 'ssrs_tracks_gather',
@@ -90,6 +92,8 @@ def lib():
         L.ssrs_traj_recorder_complete.argtypes = [C.c_void_p]
         L.ssrs_traj_recorder_used.restype = C.c_size_t
         L.ssrs_traj_recorder_used.argtypes = [C.c_void_p]
+        L.ssrs_transition_thr_bytes.restype = C.c_size_t
+        L.ssrs_transition_thr_bytes.argtypes = [C.c_int, C.c_int]
         L.ssrs_transition_ring_bytes.restype = C.c_size_t
         L.ssrs_transition_ring_bytes.argtypes = [C.c_int, C.c_int]
         if hasattr(L, 'ssrs_presence_workspace_bytes'):

@@ -224,7 +224,7 @@ __global__ void k_uniform_selftest(uint64_t seed, const uint64_t *track, const u
 }
 
 // ------------------------------------------------------------ move decision
-__device__ __forceinline__ double sum9(const double *x)
+__host__ __device__ __forceinline__ double sum9(const double *x)
 {   // numpy pairwise summation for n = 9
     return (((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]))) + x[8];
 }
@@ -635,6 +635,8 @@ struct StepArgs {
     uint32_t *visits;            // [steps][visit_stride] visited cell per slot (K3 binning), or NULL
     long long visit_stride;
     uint32_t cap;                // slots per XCD list (multiple of kBlock); list x = [x*cap, (x+1)*cap)
+    long long it_base;           // k_step_thr: global iteration of this launch's first step
+    int plane_shift;             // k_step_thr: log2 of the byte stride between the table's eight planes
     uint32_t vcap;               // slots per XCD list in the visit buffer (= cap, or the launch's own
                                  // bound when its visits are recorded for trajectory output)
     const double *thr;           // [9][9] prior-fallback thresholds (k_prior_thresholds)
@@ -1229,6 +1231,341 @@ __global__ __launch_bounds__(kBlock) void k_step_lean(const StepArgs a)
     if (lane == 0 && m) atomicAdd(&ctl->steps, m);
 }
 
+__device__ __forceinline__ void split_cell(uint32_t c, uint32_t cols, double inv_cols, uint32_t &r, uint32_t &cc)
+{
+    r = static_cast<uint32_t>(static_cast<double>(c) * inv_cols);          // c < 2^31: off by one at most
+    if (r * cols > c) --r;
+    if ((r + 1u) * cols <= c) ++r;
+    cc = c - r * cols;
+}
+
+// ------------------------------------------------------------ threshold stepper
+// k_step_lean still spends ~150 instructions and 7 wave-level branches on a step, and a wave
+// that is alone on its SIMD (100k tracks = 1.5 waves per SIMD) pays 6-9 clocks per instruction
+// and ~25 per branch whatever the instruction is (tools/microbench/latency.hip): the step is
+// bound by its instruction COUNT, not by Philox (hidden under the gather) nor by HBM.  The
+// threshold table moves everything that depends on the cell and the last move only -- picking
+// the three admissible weights, ordering them by k, summing, normalising -- into the table
+// builder.  Per (cell, last move rc) the table holds the two decision thresholds themselves,
+//     T1 = 2^24 a / (a + b + c),   T2 = 2^24 (a + b) / (a + b + c)       (f32, a b c in ascending k)
+// and a step is: one aligned 8-byte gather, two subtractions from the top 24 bits of the
+// uniform, two sign bits -> the chosen cell.  |T - 2^24 cdf_k/cdf_8| <= 0.5 (f32 rounding; the
+// f64 quotient differs from the reference's normalise-twice sequence by 1e-15) and the top-24-bit
+// uniform is within [0, 1) of 2^24 u, so whenever both |ufi - T| > 2 the decision is the
+// reference's; inside that band (2.4e-7 per boundary) the exact sequence on the raw windows
+// decides.  Everything irregular is a flag in the entry (a NaN, so the band test catches it):
+//   boundary cell      (k > burnin: the track ends; else the burn-in nudge: exact sequence)
+//   poisoned row       (a NaN / infinite weight: exact sequence, movmodel.py:228-230)
+//   reversal           (the three weights AND the masked prior are all zero: the unmasked prior
+//                       decides among its own cells, movmodel.py:239-240: thresholds thr9)
+// A row whose three weights are zero while the masked prior is not carries the PRIOR's two
+// thresholds (movmodel.py:234-238), so the common fallback needs no branch at all.  The sign
+// bit of T1 marks the cells the burn-in nudge moves (row 1, rows - 2, col cols - 2).
+// The first move of a track (eight admissible cells) is made by one iteration of the generic
+// kernel before the first launch of this one.
+constexpr uint32_t kThrPoison = 0x7FC00000u, kThrBoundary = 0x7FC00001u, kThrReversal = 0x7FC00002u;
+constexpr float kThrScale = 16777216.0f;      // 2^24
+constexpr float kThrBand = 2.0f;
+
+// The table is eight planes (one per last move rc) of 8-byte entries, plane p at byte offset
+// p << thr_plane_shift: a power-of-two stride makes a step's address one shift-or
+__host__ __device__ constexpr int thr_plane_shift(int rows, int cols)
+{
+    const unsigned long long bytes = static_cast<unsigned long long>(rows) * static_cast<unsigned long long>(cols) * 8ull;
+    int sh = 8;
+    while ((1ull << sh) < bytes) ++sh;
+    return sh;
+}
+
+struct ThrPrior {
+    float zero_t[8][2];      // thresholds of the masked prior after last move rc (scaled)
+    uint32_t reversal;       // bit rc: the masked prior is all zero as well
+    float thr9[9];           // thresholds of the unmasked prior (scaled), k = 0..8
+};
+
+__global__ __launch_bounds__(kBlock) void k_transition_thr(
+    const double *__restrict__ updraft, const float *__restrict__ potential,
+    float *__restrict__ table_out, int rows, int cols, int tiles_x, int ntiles, const ThrPrior pr, int plane_shift)
+{
+    // staging as k_transition_table: clipped reciprocals and potential of the tile + halo
+    constexpr int LW = kTabW + 2, LH = kTabH + 2;
+    __shared__ double s_inv[LW * LH];
+    __shared__ float s_pot[LW * LH];
+    const int t = xcd_band(blockIdx.x, ntiles);
+    const int r0 = (t / tiles_x) * kTabH, c0 = (t % tiles_x) * kTabW;
+    for (int i = threadIdx.x; i < LW * LH; i += kBlock) {
+        const int lr = i / LW, lc = i - lr * LW;
+        int gr = r0 - 1 + lr, gc = c0 - 1 + lc;
+        gr = gr < 0 ? 0 : (gr >= rows ? rows - 1 : gr);
+        gc = gc < 0 ? 0 : (gc >= cols ? cols - 1 : gc);
+        const size_t g = static_cast<size_t>(gr) * cols + gc;
+        const double v = updraft[g];
+        const double w = v != v ? v : (v > 1e-06 ? v : 1e-06);
+        s_inv[i] = 1.0 / w;
+        s_pot[i] = potential ? potential[g] : 0.f;
+    }
+    __syncthreads();
+    const int lc = static_cast<int>(threadIdx.x % kTabW) + 1;
+    const int col = c0 + lc - 1;
+    if (col >= cols) return;
+    for (int lr = static_cast<int>(threadIdx.x / kTabW) + 1; lr <= kTabH; lr += kBlock / kTabW) {
+        const int row = r0 + lr - 1;
+        if (row >= rows) break;
+        const size_t i = static_cast<size_t>(row) * cols + col;
+        const bool interior = row > 0 && col > 0 && row < rows - 1 && col < cols - 1;
+        float o[16];
+        if (!interior) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) o[j] = __uint_as_float(kThrBoundary);
+        } else {
+            double w[9];
+            const double ic = s_inv[lr * LW + lc];
+            const float pc = s_pot[lr * LW + lc];
+            bool bad = false;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const int q = (lr + dr_of(j)) * LW + lc + dc_of(j);
+                double v = 2.0 / (ic + s_inv[q]);                      // harmonic mean
+                if (potential) {
+                    const float d = pc - s_pot[q];
+                    const float ninv = (j == 4) ? 0.f : ((j & 1) ? 1.f : SSRS_NINV_DIAG);
+                    const float e = d * ninv;                           // stays f32
+                    v = v * static_cast<double>(e);
+                }
+                bad |= (v - v != 0.0);                                  // inf or NaN (also the centre's)
+                w[j] = v > 0.0 ? v : 0.0;                               // clip(min=0)
+            }
+            const bool zone = row == 1 || row == rows - 2 || col == cols - 2;
+#pragma unroll
+            for (int rc = 0; rc < 8; ++rc) {
+                const uint32_t ord = ring_order(rc);
+                const int ring3[3] = {(rc + 7) % 8, rc, (rc + 1) % 8};
+                const double wa = w[kRingK[ring3[ord & 3u]]], wb = w[kRingK[ring3[(ord >> 2) & 3u]]],
+                             wc = w[kRingK[ring3[(ord >> 4) & 3u]]];
+                const double ab = wa + wb, tot = ab + wc;               // np.cumsum's order
+                float t1, t2;
+                if (bad) {
+                    t1 = t2 = __uint_as_float(kThrPoison);
+                } else if (!(tot > 0.0)) {
+                    if ((pr.reversal >> rc) & 1u) t1 = t2 = __uint_as_float(kThrReversal);
+                    else { t1 = pr.zero_t[rc][0]; t2 = pr.zero_t[rc][1]; }
+                } else {
+                    double r = __builtin_amdgcn_rcp(tot);
+                    r = r * (2.0 - tot * r);                             // one Newton step: ~1e-16
+                    t1 = static_cast<float>(wa * r * static_cast<double>(kThrScale));
+                    t2 = static_cast<float>(ab * r * static_cast<double>(kThrScale));
+                    if (!(t2 <= kThrScale)) t1 = t2 = __uint_as_float(kThrPoison);   // tot overflowed
+                }
+                if (zone) t1 = __uint_as_float(__float_as_uint(t1) | 0x80000000u);
+                o[2 * rc] = t1;
+                o[2 * rc + 1] = t2;
+            }
+        }
+        // plane rc holds the entries of last move rc for all cells, 8 bytes each: neighbouring
+        // tracks (neighbouring lanes) then gather from the same few cache lines
+#pragma unroll
+        for (int rc = 0; rc < 8; ++rc)
+            *reinterpret_cast<float2 *>(reinterpret_cast<char *>(table_out) + (static_cast<size_t>(rc) << plane_shift) + i * 8) =
+                make_float2(o[2 * rc], o[2 * rc + 1]);
+    }
+}
+
+// Histogram mode of k_step_thr, a template parameter so that the loop body carries no
+// wave-uniform branches (each costs a lone wave ~25 clocks, taken or not):
+//   0 none, 1 visit buffer (plain keys), 2 visit buffer (transposed keys), 3 atomics on
+//   hist / its private copies
+template <int HM>
+__global__ __launch_bounds__(kBlock) void k_step_thr(const StepArgs a, const ThrPrior pr)
+{
+    TrackCtl *ctl = a.ctl;
+    const int in_slot = a.launch & 3, out_slot = (a.launch + 1) & 3;
+    const uint32_t xcd = blockIdx.x % kXcd;
+    const uint32_t nlive = ctl->count[in_slot][xcd];
+    const uint32_t il = (blockIdx.x / kXcd) * kBlock + threadIdx.x;
+    const uint32_t i = xcd * a.cap + il;
+    const uint32_t iv = xcd * a.vcap + il;
+    if (blockIdx.x == 0 && threadIdx.x < kXcd) ctl->count[(a.launch + 2) & 3][threadIdx.x] = 0;
+    if ((il & ~63u) >= nlive) return;
+
+    bool live0 = il < nlive;
+    const int32_t t = live0 ? (a.list_in ? a.list_in[i] : static_cast<int32_t>(i)) : 0;
+    TrackState s = {0, -1, 0, 0};
+    if (live0) s = a.state[t];
+    uint32_t rc = static_cast<uint32_t>(kRingOfK >> (4 * (s.dirs & 0xFu))) & 0xFu;
+    // (every track has made its first move before the first launch of this kernel: rc < 8)
+    live0 = live0 && s.k >= 0 && rc < 8u;
+    const uint32_t ucols = static_cast<uint32_t>(a.cols), urows = static_cast<uint32_t>(a.rows);
+    const uint32_t ncell = urows * ucols;
+    uint32_t cell = __umul24(static_cast<uint32_t>(s.pos & 0xFFFF), ucols) + (static_cast<uint32_t>(s.pos >> 16) & 0xFFFFu);
+    rc &= 7u;
+    int k = s.k;
+    // this launch covers the global iterations [it_base, it_base + steps); a track is released at
+    // global iteration delay + 1 (its first move was made before, so k - iteration stays even:
+    // one Philox block serves the even / odd pair of iterations).  A lane steps while
+    // rel <= it < rel + span; span shrinks to the iterations left until max_moves and drops to 0
+    // when the track ends.
+    const long long rel64 = (a.coherent ? static_cast<long long>(s.aux >> 9) : 0) + 1 - a.it_base;
+    const int rel = rel64 > 0x3fffffffLL ? 0x3fffffff : (rel64 < 0 ? 0 : static_cast<int>(rel64));
+    const long long left = a.max_k - k;                                          // k < max_k  <=>  it - rel < left
+    uint32_t span = !live0 ? 0u : (left > 0x3fffffffLL ? 0x3fffffffu : (left < 0 ? 0u : static_cast<uint32_t>(left)));
+    const long long burn64 = static_cast<long long>(rel) + (a.burnin - k);      // k <= burnin  <=>  it <= it_burn
+    const int it_burn = !live0 ? -1 : (burn64 > 0x3fffffffLL ? 0x3fffffff : (burn64 < -1 ? -1 : static_cast<int>(burn64)));
+    const int blk0 = (k - rel) >> 1;          // Philox block of iteration 0 (k - rel is even; negative before the release)
+    const unsigned long long track = a.track_base + static_cast<unsigned long long>(t);
+    const char *tab = reinterpret_cast<const char *>(a.table);
+    uint32_t pend_a = 0, pend_b = 0;
+    const uint32_t back = ucols + 1u;
+    // last iteration at which some lane of this wave is still in its burn-in (zone test needed)
+    int wave_burn = it_burn;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int o = __shfl_xor(wave_burn, off);
+        wave_burn = o > wave_burn ? o : wave_burn;
+    }
+    wave_burn = __builtin_amdgcn_readfirstlane(wave_burn);
+    const uint32_t psh = static_cast<uint32_t>(a.plane_shift);
+    uint2 e = *reinterpret_cast<const uint2 *>(tab + ((rc << psh) | (cell << 3)));
+    uint32_t *vrow = (HM == 1 || HM == 2) ? a.visits + iv : nullptr;              // this lane's slot, row `it`
+    uint32_t *hbase = a.hist;
+    if (HM == 3 && a.hist_copies)
+        hbase = a.hist_copies + static_cast<size_t>((i >> 6) % static_cast<uint32_t>(a.ncopies)) * static_cast<size_t>(ncell);
+    int it = 0;
+
+    auto one_step = [&](const bool even, const bool burn) {
+        // st: all ones when this lane steps now
+        const uint32_t stm = (static_cast<uint32_t>(it - rel) < span) ? 0xFFFFFFFFu : 0u;
+        uint32_t w0, w1;
+        if (even) {
+            const uint4 w4 = philox_block(a.seed, track, static_cast<unsigned long long>(static_cast<uint32_t>(blk0 + (it >> 1))));
+            w0 = w4.x; w1 = w4.y; pend_a = w4.z; pend_b = w4.w;
+        } else {
+            w0 = pend_a; w1 = pend_b;
+        }
+        const float ufi = static_cast<float>(w0 >> 8);               // top 24 bits of u, exact
+        const float d1 = ufi - __uint_as_float(e.x & 0x7FFFFFFFu), d2 = ufi - __uint_as_float(e.y);
+        float m;                                                     // min(|d1|, |d2|); NaN entries (flags) give NaN
+        asm("v_min_f32 %0, |%1|, |%2|" : "=v"(m) : "v"(d1), "v"(d2));
+        bool special = !(m > kThrBand);
+        if (burn) special = special | ((static_cast<int32_t>(e.x) < 0) & (it <= it_burn));
+        special = special & (stm != 0u);
+        const uint32_t ord = static_cast<uint32_t>(kRingOrder >> __umul24(6u, rc)) & 63u;
+        const uint32_t neg = (__float_as_uint(d1) >> 31) + (__float_as_uint(d2) >> 31);     // 2 - sel
+        uint32_t nc = (rc + 7u + ((ord >> (4u - 2u * neg)) & 3u)) & 7u;
+        uint32_t base = cell;
+        uint32_t go = stm;
+        if (__builtin_expect(__any(special), 0)) {
+            if (special) {
+                const uint32_t t1b = e.x;
+                const bool zone = static_cast<int32_t>(t1b) < 0 && k <= a.burnin;
+                bool exact = true;
+                if (t1b == kThrBoundary && k > a.burnin) {
+                    go = 0u;                                           // movmodel.py:286-288: the track ends here
+                    span = 0u;
+                    exact = false;
+                } else if (t1b == kThrReversal && !zone) {
+                    // unmasked prior (movmodel.py:239-240): count of thresholds <= u
+                    int idx = 0;
+                    bool near = false;
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) {
+                        const float d = ufi - pr.thr9[q];
+                        idx += d >= 0.f ? 1 : 0;
+                        near |= !(fabsf(d) > kThrBand);
+                    }
+                    const uint32_t pnc = static_cast<uint32_t>(kRingOfK >> (4 * (idx > 8 ? 4 : idx))) & 0xFu;
+                    if (!near && pnc < 8u) { nc = pnc; exact = false; }
+                }
+                if (exact) {
+                    // near-ties, poisoned rows, the burn-in nudge: the reference's exact sequence on
+                    // the raw windows (movmodel.py:285-312)
+                    uint32_t r, c;
+                    split_cell(cell, ucols, 1.0 / static_cast<double>(ucols), r, c);
+                    int er = static_cast<int>(r), ec = static_cast<int>(c);
+                    if (k <= a.burnin) {
+                        if (er <= 1) er += 2; else if (er >= a.rows - 2) er -= 2;
+                        if (ec <= 0) ec += 2; else if (ec >= a.cols - 2) ec -= 2;
+                    }
+                    double w[9];
+                    if (a.potential) window_weights<true>(a.updraft, a.potential, a.cols, er, ec, w);
+                    else window_weights<false>(a.updraft, a.potential, a.cols, er, ec, w);
+                    double prr[9];
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) prr[j] = a.prior[j];
+                    const uint32_t last = static_cast<uint32_t>(kKOfRing >> (4 * rc)) & 0xFu;
+                    const int idx = choose_move(w, prr, 1.0, restriction_of(last), words_to_uniform(w0, w1), false);
+                    nc = static_cast<uint32_t>(kRingOfK >> (4 * idx)) & 0xFu;
+                    base = __umul24(static_cast<uint32_t>(er), ucols) + static_cast<uint32_t>(ec);
+                }
+            }
+        }
+        // ---- move, selected with the mask (no branch: idle lanes keep cell, rc, k)
+        const uint32_t dr = (kRingDr >> (2u * nc)) & 3u, dc = (kRingDc >> (2u * nc)) & 3u;
+        const uint32_t moved_to = base + __umul24(dr, ucols) + dc - back;
+        cell = (moved_to & go) | (cell & ~go);
+        rc = (nc & go) | (rc & ~go);
+        k -= static_cast<int>(go);                                    // go is 0 or -1
+        e = *reinterpret_cast<const uint2 *>(tab + ((rc << psh) | (cell << 3)));
+        // ---- presence histogram (see k_step_tracks)
+        if (HM == 1) {
+            *vrow = cell | ~go;                                       // idle: 0xFFFFFFFF
+            vrow += a.visit_stride;
+        } else if (HM == 2) {
+            uint32_t r, c;
+            split_cell(cell, ucols, 1.0 / static_cast<double>(ucols), r, c);
+            *vrow = (__umul24(c, urows) + r) | ~go;
+            vrow += a.visit_stride;
+        } else if (HM == 3) {
+            atomicAdd(&hbase[cell], go & 1u);
+        }
+        ++it;
+    };
+    // phase A: some lane of the wave is in its burn-in (the nudge zone is live); phase B: none
+    for (; it < a.steps && it <= wave_burn; ) {            // a.steps is even (host)
+        if (!__any(static_cast<uint32_t>(it - rel) < span || it < rel)) break;
+        one_step(true, true);
+        one_step(false, true);
+    }
+    for (; it < a.steps; ) {
+        if (!__any(static_cast<uint32_t>(it - rel) < span || (it < rel && span != 0u))) break;
+        one_step(true, false);
+        one_step(false, false);
+    }
+    if (HM == 1 || HM == 2)
+        for (; it < a.steps; ++it) {
+            *vrow = 0xFFFFFFFFu;
+            vrow += a.visit_stride;
+        }
+
+    // a track whose span is used up is finished: it ended at the raster's edge or took max_moves
+    const bool active = live0 && span != 0u && k < static_cast<int>(a.max_k);
+    uint32_t row, col;
+    split_cell(cell, ucols, 1.0 / static_cast<double>(ucols), row, col);
+    if (live0 && !active) {
+        if (a.lengths) a.lengths[t] = static_cast<int32_t>(k + 1);
+        if (a.end_rc) reinterpret_cast<uint32_t *>(a.end_rc)[t] = (row & 0xFFFFu) | (col << 16);
+    }
+    const unsigned long long live = __ballot(active);
+    const int lane = threadIdx.x & 63;
+    const int nsurv = __popcll(live);
+    uint32_t basei = 0;
+    if (lane == 0 && nsurv) basei = atomicAdd(&ctl->count[out_slot][xcd], static_cast<uint32_t>(nsurv));
+    basei = __shfl(basei, 0);
+    if (active) {
+        const int rank = __popcll(live & ((1ull << lane) - 1ull));
+        a.list_out[xcd * a.cap + basei + rank] = t;
+        TrackState o;
+        o.pos = static_cast<int32_t>(row | (col << 16));
+        o.k = k;
+        o.dirs = static_cast<uint32_t>(kKOfRing >> (4 * rc)) & 0xFu;
+        o.aux = s.aux;
+        a.state[t] = o;
+    }
+    unsigned long long mv = live0 ? static_cast<unsigned long long>(k - s.k) : 0ull;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mv += __shfl_down(mv, off);
+    if (lane == 0 && mv) atomicAdd(&ctl->steps, mv);
+}
+
 // K3 binning: one block per step of the launch.  The coherent schedule keeps the
 // whole batch on a front a few raster rows deep, so one step's visits fall into
 // a window of a few rows: counted with LDS atomics, flushed with contiguous
@@ -1383,13 +1720,6 @@ constexpr int kTileRows = 30, kTileCols = 1024;              // 30 720 counters,
 constexpr int kTilesMax = 4096;                              // tiles per raster (LDS count array)
 constexpr uint32_t kItemVisits = 65536;                       // visits per k_bin_bucket block
 
-__device__ __forceinline__ void split_cell(uint32_t c, uint32_t cols, double inv_cols, uint32_t &r, uint32_t &cc)
-{
-    r = static_cast<uint32_t>(static_cast<double>(c) * inv_cols);          // c < 2^31: off by one at most
-    if (r * cols > c) --r;
-    if ((r + 1u) * cols <= c) ++r;
-    cc = c - r * cols;
-}
 
 __device__ __forceinline__ uint32_t tile_of(uint32_t c, uint32_t cols, double inv_cols, uint32_t ntc)
 {
@@ -1797,6 +2127,44 @@ namespace ssrs {
 
 using namespace ssrs;
 
+// Thresholds that depend on the heading's prior only (host, f64, the reference's sequence
+// of movmodel.py:234-244 + np.random.choice): the masked prior after each last move rc and
+// the unmasked prior.
+static void prior_tables(const double *prior, ThrPrior *out)
+{
+    auto thresholds = [](const double *q9, double *thr) {
+        double q[9];
+        const double s1 = sum9(q9);
+        for (int k = 0; k < 9; ++k) q[k] = q9[k] / s1;
+        const double s2 = sum9(q);
+        double acc = 0.0, cdf[9];
+        for (int k = 0; k < 9; ++k) { q[k] = q[k] / s2; acc = acc + q[k]; cdf[k] = acc; }
+        for (int k = 0; k < 9; ++k) thr[k] = cdf[k] / cdf[8];
+    };
+    *out = ThrPrior{};
+    for (int rc = 0; rc < 8; ++rc) {
+        const uint32_t mask = restriction(kRingK[rc]);
+        double q[9], thr[9];
+        bool any = false;
+        for (int k = 0; k < 9; ++k) {
+            q[k] = ((mask >> k) & 1u) && k != 4 ? prior[k] : 0.0;
+            any |= q[k] != 0.0;
+        }
+        if (!any) { out->reversal |= 1u << rc; continue; }
+        thresholds(q, thr);
+        // the two boundaries between the three admissible cells in ascending k
+        const uint32_t ord = ring_order(rc);
+        const int ring3[3] = {(rc + 7) % 8, rc, (rc + 1) % 8};
+        const int ka = kRingK[ring3[ord & 3u]], kb = kRingK[ring3[(ord >> 2) & 3u]];
+        out->zero_t[rc][0] = static_cast<float>(thr[ka] * static_cast<double>(kThrScale));
+        out->zero_t[rc][1] = static_cast<float>(thr[kb] * static_cast<double>(kThrScale));
+    }
+    double q[9], thr[9];
+    for (int k = 0; k < 9; ++k) q[k] = k == 4 ? 0.0 : prior[k];
+    thresholds(q, thr);
+    for (int k = 0; k < 9; ++k) out->thr9[k] = static_cast<float>(thr[k] * static_cast<double>(kThrScale));
+}
+
 extern "C" int ssrs_track_params_init(SsrsTrackParams *p, int rows, int cols,
                                       int memory_parameter, double scaling_parameter)
 {
@@ -1860,6 +2228,30 @@ extern "C" int ssrs_transition_ring_build(const double *updraft, const float *po
     const int tx = (cols + kTabW - 1) / kTabW, ty = (rows + kTabH - 1) / kTabH, nt = tx * ty;
     hipLaunchKernelGGL(k_transition_table<true>, dim3(static_cast<unsigned>(nt)), dim3(kBlock), 0,
                        as_stream(stream), updraft, potential, static_cast<void *>(ring), rows, cols, tx, nt);
+    SSRS_HIP_CHECK(hipGetLastError());
+    return SSRS_OK;
+}
+
+extern "C" size_t ssrs_transition_thr_bytes(int rows, int cols)
+{
+    if (rows <= 0 || cols <= 0) return 0;
+    return static_cast<size_t>(8) << thr_plane_shift(rows, cols);
+}
+
+extern "C" int ssrs_transition_thr_build(const double *updraft, const float *potential,
+                                         const double *prior, float *thr, int rows, int cols, void *stream)
+{
+    SSRS_REQUIRE(updraft && thr && prior, "ssrs_transition_thr_build: updraft/prior/thr is NULL");
+    SSRS_REQUIRE(rows >= 3 && cols >= 3, "ssrs_transition_thr_build: need rows, cols >= 3");
+    SSRS_REQUIRE(static_cast<size_t>(rows) * static_cast<size_t>(cols) <= (1ull << 26),
+                 "ssrs_transition_thr_build: the table is addressed with 32-bit offsets (rows * cols <= 2^26)");
+    SSRS_REQUIRE((reinterpret_cast<uintptr_t>(thr) & 63u) == 0,
+                 "ssrs_transition_thr_build: table must be 64-byte aligned");
+    ThrPrior pr;
+    prior_tables(prior, &pr);
+    const int tx = (cols + kTabW - 1) / kTabW, ty = (rows + kTabH - 1) / kTabH, nt = tx * ty;
+    hipLaunchKernelGGL(k_transition_thr, dim3(static_cast<unsigned>(nt)), dim3(kBlock), 0, as_stream(stream),
+                       updraft, potential, thr, rows, cols, tx, nt, pr, thr_plane_shift(rows, cols));
     SSRS_HIP_CHECK(hipGetLastError());
     return SSRS_OK;
 }
@@ -1980,6 +2372,18 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
     a.vcap = ws.cap;
     const bool lean = p->memory_parameter == 1 && traj == nullptr;
     const bool ring = (p->flags & SSRS_TRACKS_RING_TABLE) != 0;
+    const bool thr = (p->flags & SSRS_TRACKS_THR_TABLE) != 0;
+    ThrPrior thr_prior = {};
+    if (thr) {
+        SSRS_REQUIRE(!ring && table && updraft && lean && a.fast && (S & 1) == 0,
+                     "ssrs_tracks_simulate: SSRS_TRACKS_THR_TABLE needs table + updraft, memory_parameter 1, "
+                     "scaling_parameter 1, no direct trajectory output, no EXACT_ONLY and an even steps_per_launch");
+        SSRS_REQUIRE(static_cast<size_t>(p->rows) * static_cast<size_t>(p->cols) <= (1ull << 26),
+                     "ssrs_tracks_simulate: the threshold table needs rows * cols <= 2^26");
+        prior_tables(p->prior, &thr_prior);
+        a.plane_shift = thr_plane_shift(p->rows, p->cols);
+    }
+    const int mode0 = updraft ? (potential ? MODE_FLUIDFLOW : MODE_UPDRAFT) : MODE_PRIOR;   // thr: first move
     if (ring)
         SSRS_REQUIRE(table && updraft && lean && a.fast && (S & 1) == 0,
                      "ssrs_tracks_simulate: SSRS_TRACKS_RING_TABLE needs table + updraft, memory_parameter 1, "
@@ -2056,6 +2460,13 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
             a.launch = launch;
             a.list_in = (launch == 0 && !coherent) ? nullptr : ws.list[launch & 1];
             a.list_out = ws.list[(launch + 1) & 1];
+            // threshold table: launch 0 is ONE iteration of the window-gather kernel for every
+            // track at once (the first move has eight admissible cells), the rest are S deep
+            const bool first_move = thr && launch == 0;
+            const int Sl = first_move ? 1 : S;
+            a.steps = Sl;
+            a.coherent = (coherent && !first_move) ? 1 : 0;
+            a.it_base = thr && launch > 0 ? static_cast<long long>(launch - 1) * S : 0;
             const unsigned blocks = kXcd * ((upper + kBlock - 1) / kBlock);
             a.visits = nullptr;
             if (!binning_on && scattered && copies_ptr && !copies_live) {
@@ -2077,7 +2488,7 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                 const uint32_t vcap = (blocks / kXcd) * kBlock;
                 const bool identity = a.list_in == nullptr;
                 const size_t list_bytes = identity ? 0 : align_up(sizeof(int32_t) * kXcd * static_cast<size_t>(vcap), 256);
-                const size_t vis_bytes = align_up(sizeof(uint32_t) * kXcd * static_cast<size_t>(vcap) * static_cast<size_t>(S), 256);
+                const size_t vis_bytes = align_up(sizeof(uint32_t) * kXcd * static_cast<size_t>(vcap) * static_cast<size_t>(Sl), 256);
                 const size_t need = 256 + list_bytes + vis_bytes;
                 if (rec->bytes - rec->used < need) {
                     rec->complete = 0;           // pool exhausted: the rest of the run is not recorded
@@ -2090,7 +2501,7 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                     ch.visits = reinterpret_cast<const uint32_t *>(base + 256 + list_bytes);
                     ch.vcap = vcap;
                     ch.cap = ws.cap;
-                    ch.steps = S;
+                    ch.steps = Sl;
                     ch.transposed = (hist_t && binning_on) ? 1 : 0;
                     hipError_t e1 = hipMemcpyAsync(base, ws.ctl->count[launch & 3], kXcd * sizeof(uint32_t),
                                                    hipMemcpyDeviceToDevice, st);
@@ -2110,8 +2521,15 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                 hipEvent_t e;
                 if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); ev_prof.push_back(e); }
             }
-            switch (mode) {
+            switch (first_move ? mode0 : mode) {
             case MODE_TABLE:
+                if (thr) {
+                    if (a.visits && hist_t && binning_on) hipLaunchKernelGGL((k_step_thr<2>), dim3(blocks), dim3(kBlock), 0, st, a, thr_prior);
+                    else if (a.visits) hipLaunchKernelGGL((k_step_thr<1>), dim3(blocks), dim3(kBlock), 0, st, a, thr_prior);
+                    else if (a.hist) hipLaunchKernelGGL((k_step_thr<3>), dim3(blocks), dim3(kBlock), 0, st, a, thr_prior);
+                    else hipLaunchKernelGGL((k_step_thr<0>), dim3(blocks), dim3(kBlock), 0, st, a, thr_prior);
+                    break;
+                }
                 // (the zero-mask variant only pays under in-stepper atomics: with tile buckets it
                 // was measured slower, 7.0 -> 8.3 s per 100k wandering tracks)
                 if (ring && scattered && !binning_on && !tiles_on) hipLaunchKernelGGL((k_step_lean<true, true>), dim3(blocks), dim3(kBlock), 0, st, a);
@@ -2134,10 +2552,10 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                 hipEvent_t b0 = nullptr, b1 = nullptr;
                 if (profile && hipEventCreate(&b0) == hipSuccess) (void)hipEventRecord(b0, st);
                 if (hist_t)
-                    hipLaunchKernelGGL(k_bin_visits, dim3(S), dim3(kBinThreads), 0, st, a.visits, a.visit_stride,
+                    hipLaunchKernelGGL(k_bin_visits, dim3(Sl), dim3(kBinThreads), 0, st, a.visits, a.visit_stride,
                                        ws.ctl, launch & 3, hist_t, p->cols, p->rows, a.vcap);
                 else
-                    hipLaunchKernelGGL(k_bin_visits, dim3(S), dim3(kBinThreads), 0, st, a.visits, a.visit_stride,
+                    hipLaunchKernelGGL(k_bin_visits, dim3(Sl), dim3(kBinThreads), 0, st, a.visits, a.visit_stride,
                                        ws.ctl, launch & 3, hist, p->rows, p->cols, a.vcap);
                 if (profile && b0 && hipEventCreate(&b1) == hipSuccess) {
                     (void)hipEventRecord(b1, st);
@@ -2152,16 +2570,16 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                 const double inv_cols = 1.0 / static_cast<double>(p->cols);
                 const uint32_t ucols = static_cast<uint32_t>(p->cols), ucell = static_cast<uint32_t>(ncell);
                 (void)hipMemsetAsync(ws.tile_count, 0, sizeof(uint32_t) * ntiles, st);
-                hipLaunchKernelGGL((k_tile_sort<false>), dim3(blocks, kStepSplit), dim3(kBlock), 0, st, a.visits, a.visit_stride, S,
+                hipLaunchKernelGGL((k_tile_sort<false>), dim3(blocks, kStepSplit), dim3(kBlock), 0, st, a.visits, a.visit_stride, Sl,
                                    ws.ctl, launch & 3, ucols, inv_cols, ucell, a.vcap, ntc, ntiles, ws.tile_count,
                                    ws.tile_cursor, ws.bucket);
                 hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(kTileThreads), 0, st, ws.tile_count, ntiles, ws.tile_start,
                                    ws.tile_cursor, ws.item_start);
-                hipLaunchKernelGGL((k_tile_sort<true>), dim3(blocks, kStepSplit), dim3(kBlock), 0, st, a.visits, a.visit_stride, S,
+                hipLaunchKernelGGL((k_tile_sort<true>), dim3(blocks, kStepSplit), dim3(kBlock), 0, st, a.visits, a.visit_stride, Sl,
                                    ws.ctl, launch & 3, ucols, inv_cols, ucell, a.vcap, ntc, ntiles, ws.tile_count,
                                    ws.tile_cursor, ws.bucket);
                 // at most S visits per slot of the launch, and one partly filled item per tile
-                const unsigned long long max_visits = static_cast<unsigned long long>(blocks) * kBlock * S;
+                const unsigned long long max_visits = static_cast<unsigned long long>(blocks) * kBlock * Sl;
                 const unsigned items = static_cast<unsigned>(max_visits / kItemVisits) + ntiles;
                 hipLaunchKernelGGL(k_bin_bucket, dim3(items), dim3(kTileThreads), 0, st, ws.bucket, ws.tile_start,
                                    ws.tile_count, ws.ctl, hist, static_cast<uint32_t>(p->rows), ucols, inv_cols, ntc,
@@ -2173,7 +2591,7 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                 }
             }
             if (rec_counts && hist && !binning_on && !tiles_on)      // recorded launch outside both binning paths
-                hipLaunchKernelGGL(k_count_visits, dim3(blocks), dim3(kBlock), 0, st, a.visits, a.vcap, S, rec_counts, hist,
+                hipLaunchKernelGGL(k_count_visits, dim3(blocks), dim3(kBlock), 0, st, a.visits, a.vcap, Sl, rec_counts, hist,
                                    static_cast<uint32_t>(ncell));
             if (hipGetLastError() != hipSuccess) { rc = set_error(SSRS_ERR_HIP, "stepper launch failed"); break; }
         }

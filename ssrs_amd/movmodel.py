@@ -76,7 +76,7 @@ def get_directional_probs(theta):
 
 def make_track_params(grid_shape, move_dirn, memory_parameter=1, scaling_parameter=1.,
                       steps_per_launch=0, profile=False, exact_only=False, schedule=True,
-                      binning=True, ring=False, scattered=None):
+                      binning=True, ring=False, scattered=None, thr=False):
     rows, cols = int(grid_shape[0]), int(grid_shape[1])
     p = nat.SsrsTrackParams()
     nat.check(nat.lib().ssrs_track_params_init(C.byref(p), rows, cols, int(memory_parameter),
@@ -90,19 +90,47 @@ def make_track_params(grid_shape, move_dirn, memory_parameter=1, scaling_paramet
         (0 if schedule else nat.SSRS_TRACKS_NO_SCHEDULE) | \
         (0 if binning else nat.SSRS_TRACKS_NO_BINNING) | \
         (nat.SSRS_TRACKS_RING_TABLE if ring else 0) | \
+        (nat.SSRS_TRACKS_THR_TABLE if thr else 0) | \
         (0 if scattered is None else (nat.SSRS_TRACKS_SCATTERED if scattered else nat.SSRS_TRACKS_NO_SCATTERED))
     return p
 
 
-def build_transition_table(updraft, potential, ring=False):
+THR_MAX_CELLS = 1 << 26        # the threshold table is addressed with 32-bit offsets
+
+
+def table_kind(table):
+    """'f64' | 'ring' | 'thr' | None for a tensor made by build_transition_table."""
+    if table is None:
+        return None
+    if table.dtype == torch.float64:
+        return 'f64'
+    return getattr(table, '_ssrs_kind', 'ring')
+
+
+def build_transition_table(updraft, potential, ring=False, thr=False, move_dirn=None):
     """Per-cell move weights for the table stepper: 8 x f64 per cell (any
-    memory_parameter), or with ring=True the f32 ring table (10 x f32 per cell, a
-    1-D float32 tensor) of the three-candidate stepper (memory_parameter 1)."""
+    memory_parameter); with ring=True the f32 ring table (10 x f32 per cell, a
+    1-D float32 tensor) of the three-candidate stepper; with thr=True the threshold table
+    (16 x f32 per cell: the two decision thresholds for each of the eight last moves) of the
+    threshold stepper -- it belongs to ONE heading, `move_dirn` (degrees).  Both f32 forms
+    serve memory_parameter 1 / nu 1 only."""
     upd = to_dev(updraft, torch.float64)
     pot = to_dev(potential, torch.float32)
     rows, cols = int(upd.shape[0]), int(upd.shape[1])
     if pot is not None and tuple(pot.shape) != (rows, cols):
         raise ValueError('updraft and potential shapes differ')
+    if thr:
+        if move_dirn is None:
+            raise ValueError('the threshold table needs move_dirn (it holds the prior fallback of that heading)')
+        prior = np.ascontiguousarray(get_directional_probs(float(move_dirn) * np.pi / 180.), dtype=np.float64)
+        nbytes = nat.lib().ssrs_transition_thr_bytes(rows, cols)
+        table = torch.empty(nbytes // 4, dtype=torch.float32, device=upd.device)
+        nat.check(nat.lib().ssrs_transition_thr_build(
+            nat.ptr(upd), nat.ptr(pot), prior.ctypes.data_as(C.POINTER(C.c_double)), nat.ptr(table),
+            rows, cols, stream_ptr()))
+        table._ssrs_kind = 'thr'
+        table._ssrs_dirn = float(move_dirn)
+        return table
     if ring:
         nbytes = nat.lib().ssrs_transition_ring_bytes(rows, cols)
         table = torch.empty(nbytes // 4, dtype=torch.float32, device=upd.device)
@@ -129,7 +157,7 @@ def default_record_pool_bytes(n, rows, cols):
     bounded by a quarter of the free HBM (the pool is only scratch: when it runs out the
     run falls back to the two-pass form)."""
     free, _ = torch.cuda.mem_get_info()
-    want = int(n) * 4 * max(int(rows), int(cols)) * 3 + (64 << 20)
+    want = max(int(n) * 4 * max(int(rows), int(cols)) * 3, 1 << 30)     # small batches: lists pad to 256 slots
     return int(max(1 << 20, min(want, free // 4))) // 256 * 256
 
 
@@ -158,7 +186,7 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
                     seed=0, track_id_base=0, table=None, use_table=None, hist=None,
                     want_hist=True, want_tracks=False, steps_per_launch=0, profile=False,
                     exact_only=False, schedule=True, binning=True, ring=None, scattered=None,
-                    max_moves=None, record=True, record_pool_bytes=None):
+                    max_moves=None, record=True, record_pool_bytes=None, thr=None):
     """generate_simulated_tracks for a whole batch (movmodel.py:264-318 under
     simulator.py:360-369) + presence histogram (movmodel.py:410-419).
 
@@ -167,7 +195,9 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
     build_transition_table) or use_table=True selects the one-fetch-per-step
     path; default: table when it pays (many steps per cell).  A float32
     `table` is the ring table (build_transition_table(..., ring=True)); when the
-    table is built here, ring=None picks it whenever it applies (memory 1, nu 1).
+    table is built here, the threshold table (build_transition_table(..., thr=True)) is
+    picked whenever it applies (memory 1, nu 1, rows * cols < 2^26); ring=True / thr=False
+    ask for the ring table, ring=False for the f64 table.
     `hist` (int32/uint32 CUDA tensor) is accumulated into when given.
 
     want_tracks: trajectories (TrackBatch.tracks()).  record=True (default) keeps every
@@ -196,18 +226,25 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
             # takes more steps than that (>= ~rows steps per track)
             use_table = n * rows >= 4 * rows * cols
         if use_table:
+            f32_ok = ring_table_applies(memory_parameter, scaling_parameter, two_pass,
+                                        exact_only, steps_per_launch)
+            if thr is None:
+                thr = f32_ok and ring is None and rows * cols < THR_MAX_CELLS
             if ring is None:
-                ring = ring_table_applies(memory_parameter, scaling_parameter, two_pass,
-                                          exact_only, steps_per_launch)
-            table = build_transition_table(upd, pot, ring=bool(ring))
+                ring = f32_ok and not thr
+            table = build_transition_table(upd, pot, ring=bool(ring) and not thr, thr=bool(thr),
+                                           move_dirn=move_dirn)
+    is_thr = table_kind(table) == 'thr'
+    if is_thr and getattr(table, '_ssrs_dirn', float(move_dirn)) != float(move_dirn):
+        raise ValueError('this threshold table was built for another move_dirn')
     is_ring = table is not None and table.dtype == torch.float32
     if is_ring and not ring_table_applies(memory_parameter, scaling_parameter, two_pass,
                                           exact_only, steps_per_launch):
         raise ValueError('the ring table needs memory_parameter 1, scaling_parameter 1, no '
                          'two-pass trajectory output, exact_only=False and an even steps_per_launch')
     p = make_track_params((rows, cols), move_dirn, memory_parameter, scaling_parameter,
-                          steps_per_launch, profile, exact_only, schedule, binning, ring=is_ring,
-                          scattered=scattered)
+                          steps_per_launch, profile, exact_only, schedule, binning,
+                          ring=is_ring and not is_thr, scattered=scattered, thr=is_thr)
     if max_moves is not None:          # probe hook: cap below the reference's R/2 * C/2 (movmodel.py:277)
         p.max_moves = int(max_moves)
     if hist is None and want_hist:

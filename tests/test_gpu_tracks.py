@@ -660,3 +660,121 @@ def test_record_pool_overflow_falls_back_to_two_passes(gpu):
     two = movmodel.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=4, use_table=True,
                                    want_tracks=True, record=False)
     assert not two.stats['recorded'] and torch.equal(two.traj, res.traj)
+
+
+# -------------------------------------------------------------- threshold table
+# The threshold table (two decision thresholds per cell and last move, one 8-byte gather and
+# two comparisons per step) is the default stepper path; like the ring table it must give the
+# reference's tracks bit for bit, handing near-ties and flagged rows to the exact sequence.
+
+def test_thr_table_c1_golden(gpu, golden):
+    from ssrs_amd import movmodel, layers
+    g = golden('g8_c1.npz')
+    upd = layers.get_above_threshold_speed(g['orograph_f32'], 0.75)
+    starts = np.stack([g['start_rows'], g['start_cols']], 1)
+    for spl in (0, 64, 2):
+        res = movmodel.simulate_tracks(0., starts, (500, 600), 1, 1., upd, g['potential'],
+                                       seed=int(g['seed']), use_table=True, thr=True, steps_per_launch=spl)
+        lens, ends, hist = _no_traj_result(res)
+        assert np.array_equal(lens, g['lengths'])
+        assert np.array_equal(ends, g['ends'])
+        assert np.array_equal(hist, g['hist'].view(np.uint32))
+    rec = movmodel.simulate_tracks(0., starts, (500, 600), 1, 1., upd, g['potential'], seed=int(g['seed']),
+                                   use_table=True, thr=True, want_tracks=True)
+    assert rec.stats['recorded']
+    sha = hashlib.sha256()
+    for t in rec.tracks():
+        sha.update(np.ascontiguousarray(t, dtype='<i2').tobytes())
+    assert sha.hexdigest() == str(g['traj_sha256'])
+
+
+@pytest.mark.parametrize('tag', ['ff_m1', 'ff_d135_m2', 'ff_m1_nu05'])
+def test_thr_table_g7_cases(gpu, golden, tag):
+    """G7 starts include border rows: the burn-in nudge goes through the flagged entries."""
+    from ssrs_amd import movmodel
+    g = golden('g7_tracks.npz')
+    dirn, mem, nu, has_u, has_p = g[tag + '_params']
+    starts = np.stack([g['start_rows'], g['start_cols']], 1)
+    args = (float(dirn), starts, (96, 128), int(mem), float(nu), g['updraft'],
+            g['potential'] if has_p else None)
+    if int(mem) == 1 and float(nu) == 1.0:
+        res = movmodel.simulate_tracks(*args, seed=int(g['seed']), use_table=True, thr=True,
+                                       steps_per_launch=16, want_tracks=True)
+        assert np.array_equal(res.lengths.cpu().numpy(), g[tag + '_lengths'])
+        for a, b in zip(res.tracks(), split(g[tag + '_tracks'], g[tag + '_lengths'])):
+            assert np.array_equal(a, b)
+    else:
+        with pytest.raises(ValueError):
+            movmodel.simulate_tracks(*args, seed=int(g['seed']), use_table=True, thr=True)
+
+
+@pytest.mark.parametrize('case', ['rough', 'nan_zero', 'updraft_only', 'tiny', 'huge', 'flat', 'south'])
+def test_thr_table_vs_c_oracle(gpu, case):
+    """Fresh inputs incl. every flagged kind of row: NaN (poisoned) and all-zero rows (masked prior
+    thresholds), weights below the f32 range and beyond it, a flat potential (the prior decides
+    every step) and a heading against which the masked prior vanishes (reversal rows)."""
+    from ssrs_amd import movmodel
+    from oracle import c_oracle
+    rows, cols = 150, 170
+    upd, pot = _random_field_case(rows, cols, 31)
+    dirn = 20.
+    if case == 'nan_zero':
+        upd = upd.copy(); pot = pot.copy()
+        upd[20:25, 30:40] = np.nan
+        pot[60:62, 10:160] = np.nan
+        pot[90:110, :] = 3.0                       # zero differences
+    elif case == 'updraft_only':
+        pot = None
+    elif case == 'tiny':
+        pot = (pot.astype(np.float64) * 1e-37).astype(np.float32)
+    elif case == 'huge':
+        upd = upd * 1e30
+        pot = (pot.astype(np.float64) * 1e30).astype(np.float32)
+    elif case == 'flat':
+        pot = np.full_like(pot, 7.0)
+    elif case == 'south':
+        dirn = 180.                                # the potential still pulls north: reversals
+        pot = pot.copy()
+        pot[40:110, :] = pot[40, 0]
+    rng = np.random.default_rng(5)
+    n = 900
+    starts = np.stack([rng.integers(0, rows, n), rng.integers(0, cols, n)], 1)
+    ref = c_oracle.simulate_tracks(dirn, starts, (rows, cols), 1, 1., upd, pot, seed=11,
+                                   track_id_base=77, want_traj=False)
+    for scattered in (None, True):
+        res = movmodel.simulate_tracks(dirn, starts, (rows, cols), 1, 1., upd, pot, seed=11,
+                                       track_id_base=77, use_table=True, thr=True,
+                                       scattered=scattered, steps_per_launch=32)
+        lens, ends, hist = _no_traj_result(res)
+        assert np.array_equal(lens, ref['lengths']), (case, scattered)
+        assert np.array_equal(ends, ref['ends']), (case, scattered)
+        assert np.array_equal(hist, ref['hist']), (case, scattered)
+
+
+def test_thr_table_large_batch_equals_f64_table(gpu):
+    from ssrs_amd import movmodel
+    rows, cols = 600, 900
+    upd, pot = _random_field_case(rows, cols, 3)
+    rng = np.random.default_rng(8)
+    n = 20000
+    starts = np.stack([rng.integers(1, 12, n), rng.integers(0, cols, n)], 1)
+    for dirn in (0., 90., 45.):
+        a = _no_traj_result(movmodel.simulate_tracks(dirn, starts, (rows, cols), 1, 1., upd, pot, seed=3,
+                                                     use_table=True, ring=False))
+        res = movmodel.simulate_tracks(dirn, starts, (rows, cols), 1, 1., upd, pot, seed=3, use_table=True, thr=True)
+        assert movmodel.table_kind is not None
+        b = _no_traj_result(res)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), dirn
+        assert int(b[2].sum()) == int(b[0].sum())
+
+
+def test_thr_table_belongs_to_one_heading(gpu):
+    from ssrs_amd import movmodel
+    upd, pot = _random_field_case(40, 50, 1)
+    table = movmodel.build_transition_table(upd, pot, thr=True, move_dirn=0.)
+    assert movmodel.table_kind(table) == 'thr'
+    with pytest.raises(ValueError):
+        movmodel.simulate_tracks(90., [[5, 5]], (40, 50), 1, 1., upd, pot, table=table)
+    with pytest.raises(ValueError):
+        movmodel.build_transition_table(upd, pot, thr=True)

@@ -13,7 +13,7 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
     dem = torch.from_numpy(synthetic_dem(shape, 10.)).cuda()
     pot = torch.from_numpy(ramp_potential(shape)).cuda()
     _, upd = layers.updraft_from_dem(dem, 10., 10., 270., threshold=0.75)
-    table = movmodel.build_transition_table(upd, pot, ring=True)
+    table = movmodel.build_transition_table(upd, pot, ring=True) if os.environ.get('PROBE_TABLE') == 'ring' else movmodel.build_transition_table(upd, pot, thr=True, move_dirn=0.)
     np.random.seed(30)
     r, c = movmodel.get_starting_indices(100000, (5, 55, 1, 2), 'random', (60., 50.), 10.)
     starts = np.stack([r, c], 1)
