@@ -50,6 +50,8 @@ def parse():
     ap.add_argument('--solve-iterations', type=int, default=2000)
     ap.add_argument('--solved-tracks', type=int, default=10_000,
                     help='tracks of the solved_potential leg (outside the timed region; 0 = skip)')
+    ap.add_argument('--no-chain-probe', action='store_true',
+                    help='skip the 16 384-track dependent-chain measurement (profiling runs: keeps per-kernel averages clean)')
     ap.add_argument('--ref-cpu-tracks', type=int, default=3,
                     help='tracks of the reference-equivalent (numpy restatement) CPU rate (0 = skip)')
     ap.add_argument('--no-binning', action='store_true', help='per-step global atomics for the histogram')
@@ -422,7 +424,7 @@ def main():
                                                  + str(rec.get('source')))
         except Exception:
             pass
-    if world == 1 and not args.direct:
+    if world == 1 and not args.direct and not args.no_chain_probe:
         out['roofline']['dependent_chain'] = chain_probe(args, movmodel, layers, dem, pot, starts_h, gridsize, res, seed)
     if world == 1 and args.solved_tracks > 0 and args.potential != 'solve':
         out['solved_potential'] = solved_leg(args, movmodel, layers, dem, starts_h, gridsize, res, seed)

@@ -304,6 +304,15 @@ int ssrs_tracks_gather(const SsrsTrajRecorder *recorder, const int32_t *start_rc
                        int64_t ntracks, const int64_t *traj_offsets, int16_t *traj,
                        void *cursor_ws, size_t cursor_bytes, void *stream);
 
+/* The one exchange step of a track-sharded run (the reference maps the tracks of a
+ * case over a process pool, simulator.py:360-369, and adds them up in compute_presence_counts):
+ * in-place sum of the ranks' uint32 histograms over xGMI.  `nccl_comm` is an ncclComm_t the caller
+ * created with its own RCCL (one process per GPU); root >= 0: ncclReduce to that rank, root < 0:
+ * ncclAllReduce.  Asynchronous on `stream`.  RCCL is resolved at run time (the process's own copy
+ * first, else librccl.so.1), so the library loads without it.  The sum is 32-bit: a caller whose
+ * ranks' largest counts add up to 2^32 or more must widen first (ssrs_amd.distributed does). */
+int ssrs_hist_reduce(uint32_t *hist, size_t n, int root, void *nccl_comm, void *stream);
+
 /* --------------------------------------------------------------- presence */
 
 /* compute_presence_counts (ssrs/movmodel.py:410-419) from stored trajectories:

@@ -65,7 +65,7 @@ def uniform(seed, track, step):
 
 def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
                     scaling_parameter=1.0, updraft=None, potential=None, seed=0,
-                    track_id_base=0, want_traj=True, want_hist=True, nthreads=0):
+                    track_id_base=0, want_traj=True, want_hist=True, nthreads=0, max_moves=None):
     """Returns dict(lengths int32[n], ends int16[n,2], hist uint32[R,C] | None,
     tracks list[int16[n_i,2]] | None, steps int)."""
     L = lib()
@@ -73,6 +73,8 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
     starts = np.ascontiguousarray(np.asarray(starts, dtype=np.int32).reshape(-1, 2))
     n = starts.shape[0]
     p = make_params(grid_shape, move_dirn, memory_parameter, scaling_parameter)
+    if max_moves is not None:      # test hook: cap below the reference's R/2 * C/2 (movmodel.py:277)
+        p.max_moves = float(max_moves)
     upd = None if updraft is None else np.ascontiguousarray(updraft, dtype=np.float64)
     pot = None if potential is None else np.ascontiguousarray(potential, dtype=np.float32)
     if upd is not None:

@@ -39,7 +39,7 @@ def build(force=False, verbose=False):
     for s, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f'hipcc failed on {s}')
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + ['-ldl']
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)

@@ -1,0 +1,120 @@
+"""BASELINE configs[3] (snapshot mode) and the per-GPU share of configs[4] (seasonal mode) AT
+THEIR SIZE, 5000 x 6000 @10 m: raster properties on the full grid and a
+sample of tracks against the C oracle on the same rasters
+(/root/reference/ssrs/simulator.py:200-215 wind cases -> orographs, :348-369 tracks per case).
+Track lengths are capped below max_moves = 7.5e6 (on the solved field a third of the tracks
+wander to it, tests/golden/g11_wander.npz pins that regime); the cap is applied to both sides."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+SHAPE, RES = (5000, 6000), 10.
+
+
+def _ulp(a, b):
+    return (a.view(torch.int32).long() - b.view(torch.int32).long()).abs()
+
+
+@pytest.fixture(scope='module')
+def c2_dem():
+    from ssrs_amd.synthetic import synthetic_dem
+    return torch.from_numpy(synthetic_dem(SHAPE, RES)).cuda()
+
+
+def test_config3_snapshot_raster_and_tracks_at_full_size(gpu, c2_dem):
+    from ssrs_amd import layers, movmodel
+    from ssrs_amd.potential import solve_potential
+    from ssrs_amd.synthetic import wind_lattice
+    from ssrs_amd.wind import interpolate_wind_lattice
+    from oracle import c_oracle
+    x, y, ws, wd = wind_lattice((60., 50.), 2.0)
+    assert ws.shape == (26, 31)                    # 31 x 26 points on a 2 km lattice
+    # K1: the fused DEM + lattice kernel equals the three-kernel chain through per-cell wind rasters
+    oro, upd = layers.updraft_from_dem_lattice(c2_dem, RES, x, y, ws, wd, threshold=0.75)
+    s_r, d_r = interpolate_wind_lattice(x, y, ws, wd, SHAPE, RES)
+    slope, aspect = layers.slope_aspect(c2_dem, RES)
+    oro2, upd2 = layers.orographic_updraft(s_r, d_r, slope, aspect, threshold=0.75)
+    u = _ulp(oro, oro2)
+    # <= 1 f32 ulp except where the value is cancellation noise (|w| ~ 1e-15 m/s)
+    big = u > 1
+    assert float(big.double().mean()) < 5e-3
+    assert float((oro - oro2).abs()[big].max()) < 1e-12 if bool(big.any()) else True
+    assert float((upd - upd2).abs().max()) < 1e-6
+    del s_r, d_r, slope, aspect, oro2, upd2
+    # K5 + K2/K3: 256 tracks of the snapshot case, GPU vs the C oracle on the SAME rasters
+    pot, st = solve_potential(upd, 0., return_stats=True)
+    assert st['converged'], st
+    np.random.seed(30)
+    r, c = movmodel.get_starting_indices(100_000, (5, 55, 1, 2), 'random', (60., 50.), RES)
+    starts = np.stack([r, c], 1)[:256]
+    cap = 30_000
+    upd_h, pot_h = upd.cpu().numpy(), pot.cpu().numpy()
+    ref = c_oracle.simulate_tracks(0., starts, SHAPE, 1, 1., upd_h, pot_h, seed=30, want_traj=False,
+                                   max_moves=cap)
+    for kw in (dict(), dict(ring=True), dict(use_table=False)):
+        got = movmodel.simulate_tracks(0., starts, SHAPE, 1, 1., upd, pot, seed=30, use_table=kw.pop('use_table', True),
+                                       max_moves=cap, **kw)
+        assert np.array_equal(got.lengths.cpu().numpy(), ref['lengths']), kw
+        assert np.array_equal(got.ends.cpu().numpy(), ref['ends']), kw
+        assert torch.equal(got.hist.cpu(), torch.from_numpy(ref['hist'].view(np.int32))), kw
+    L = ref['lengths'] - 1
+    print(f'config 3 sample: steps median {np.median(L):.0f}, at the cap {np.mean(L >= cap):.2f}; solve {st}')
+
+
+def test_config4_share_batched_rasters_and_concurrent_snapshots(gpu, c2_dem):
+    """One GPU's share of the seasonal config: 32 wind snapshots through K1 in batches of 16 (the
+    DEM is read once per batch), then several snapshots' fluidflow tracks stepped CONCURRENTLY, one
+    host thread and HIP stream each (Simulator.simulate_tracks does the same), each checked against
+    the C oracle on a sample."""
+    from ssrs_amd import layers, movmodel
+    from ssrs_amd.potential import solve_potential
+    from ssrs_amd.synthetic import wind_lattice
+    from oracle import c_oracle
+    lat = [wind_lattice((60., 50.), 2.0, phase=2 * np.pi * s / 256) for s in range(32)]
+    x, y = lat[0][0], lat[0][1]
+    ws = np.stack([l[2] for l in lat])
+    wd = np.stack([l[3] for l in lat])
+    oros = []
+    for b0 in range(0, 32, 16):
+        oro, _ = layers.updraft_from_dem_lattice(c2_dem, RES, x, y, ws[b0:b0 + 16], wd[b0:b0 + 16])
+        oros.append(oro)
+    oros = torch.cat(oros)
+    assert tuple(oros.shape) == (32,) + SHAPE
+    for s in (0, 15, 16, 31):                         # a batch member equals its single-snapshot run
+        single, _ = layers.updraft_from_dem_lattice(c2_dem, RES, x, y, ws[s], wd[s])
+        assert torch.equal(single, oros[s])
+    assert not torch.equal(oros[0], oros[1])
+    # three snapshots: potential, then 2000 tracks each on three threads / streams at once
+    np.random.seed(30)
+    r, c = movmodel.get_starting_indices(10_000, (5, 55, 1, 2), 'random', (60., 50.), RES)
+    starts = np.stack([r, c], 1)[:2000]
+    cap = 20_000
+    fields = []
+    for s in (0, 9, 21):
+        upd = layers.get_above_threshold_speed(oros[s], 0.75)
+        pot = solve_potential(upd, 0., rel_tol=1e-8)          # parity vs the oracle needs the same field, not a converged one
+        fields.append((s, upd, pot))
+    del oros
+    results = {}
+
+    def run(s, upd, pot):
+        with torch.cuda.stream(torch.cuda.Stream()):
+            results[s] = movmodel.simulate_tracks(0., starts, SHAPE, 1, 1., upd, pot, seed=1000 + s, use_table=True,
+                                                  max_moves=cap)
+            torch.cuda.current_stream().synchronize()
+
+    threads = [threading.Thread(target=run, args=f) for f in fields]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for s, upd, pot in fields:
+        ref = c_oracle.simulate_tracks(0., starts[:200], SHAPE, 1, 1., upd.cpu().numpy(), pot.cpu().numpy(),
+                                       seed=1000 + s, want_traj=False, want_hist=False, max_moves=cap)
+        got = results[s]
+        assert np.array_equal(got.lengths.cpu().numpy()[:200], ref['lengths']), s
+        assert np.array_equal(got.ends.cpu().numpy()[:200], ref['ends']), s
+        assert int(got.hist.sum()) == int(got.lengths.sum())

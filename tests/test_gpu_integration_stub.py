@@ -86,3 +86,39 @@ def test_integration_md_stub_runs_and_matches_oracle(gpu):
                                   C.c_uint64(1), C.c_uint64(0), p(hist), p(ends), p(lengths), None, None,
                                   p(ws), C.c_size_t(nb), None, STREAM())
     assert rc != 0 and b'RING_TABLE' in lib.ssrs_last_error()
+
+
+def test_hist_reduce_through_the_c_abi_with_a_callers_rccl_communicator(gpu):
+    """ssrs_hist_reduce: a C-ABI consumer brings its own ncclComm_t.  One GPU here,
+    so the communicator has one rank (RCCL refuses two ranks on one device): the call must go
+    through RCCL and leave the counts intact, for ncclReduce and ncclAllReduce; the multi-rank sum
+    itself is RCCL's (the driver's 8-GPU run exercises it through torch.distributed)."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from ssrs_amd import _native as nat
+    rccl = C.CDLL('librccl.so.1', mode=C.RTLD_GLOBAL)      # the caller's RCCL, visible to the library
+
+    class UniqueId(C.Structure):
+        _fields_ = [('internal', C.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        rng = np.random.default_rng(3)
+        h = rng.integers(0, 2 ** 32, size=(300, 400), dtype=np.uint64).astype(np.uint32)
+        t = torch.from_numpy(h.view(np.int32).copy()).cuda()
+        stream = torch.cuda.current_stream()
+        for root in (0, -1):
+            nat.check(nat.lib().ssrs_hist_reduce(nat.ptr(t), C.c_size_t(t.numel()), root, comm,
+                                                 C.c_void_p(stream.cuda_stream)))
+            stream.synchronize()
+            assert np.array_equal(t.cpu().numpy().view(np.uint32), h)
+        with pytest.raises(ValueError):
+            nat.check(nat.lib().ssrs_hist_reduce(nat.ptr(t), C.c_size_t(t.numel()), 0, None, None))
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
