@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SSRS_VERSION 100 /* 0.1.0 */
+#define SSRS_VERSION 101 /* 0.1.1 */
 
 #define SSRS_OK 0
 #define SSRS_ERR_INVALID (-1) /* bad argument (message says which) */
@@ -358,6 +358,8 @@ typedef struct SsrsSolveStats {
     float kernel_ms;
     int32_t amg_levels;   /* levels of the aggregation hierarchy (0 = none) */
     int32_t amg_coarsest; /* nodes on its last level */
+    float setup_ms;       /* building the hierarchy (not part of kernel_ms) */
+    uint64_t workspace_used; /* bytes of `workspace` really touched (the size query is an upper bound) */
 } SsrsSolveStats;
 
 #define SSRS_SOLVE_NO_AMG 1  /* plain BiCGStab (A/B switch; stalls on real rasters) */
@@ -370,6 +372,9 @@ typedef struct SsrsSolveStats {
 /* flags bits 4-6: extra pairs of Jacobi sweeps; bits 8-11: strict matching rounds of
  * the one-sided criterion (0 = 4) */
 
+/* Device scratch that always suffices (about 1.5 KB per cell).  The hierarchy really takes ~840 B
+ * per cell (SsrsSolveStats.workspace_used reports it); a smaller workspace is accepted and the call
+ * fails with SSRS_ERR_INVALID ("workspace exhausted") when it does not suffice. */
 size_t ssrs_potential_workspace_bytes(int rows, int cols);
 
 /* MovModel.assemble_sparse_linear_system + solve_sparse_linear_system

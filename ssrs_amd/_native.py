@@ -56,7 +56,8 @@ class SsrsTrackStats(C.Structure):
 class SsrsSolveStats(C.Structure):
     _fields_ = [('iterations', C.c_int32), ('converged', C.c_int32),
                 ('residual', C.c_double), ('kernel_ms', C.c_float),
-                ('amg_levels', C.c_int32), ('amg_coarsest', C.c_int32)]
+                ('amg_levels', C.c_int32), ('amg_coarsest', C.c_int32),
+                ('setup_ms', C.c_float), ('workspace_used', C.c_uint64)]
 
 
 class SsrsError(RuntimeError):

@@ -482,7 +482,10 @@ typedef struct SsrsSolveStatsInternal {
     double residual;
     float kernel_ms;
     int32_t amg_levels, amg_coarsest;
+    float setup_ms;
+    uint64_t workspace_used;
 } SsrsSolveStatsInternal;
+static_assert(sizeof(SsrsSolveStatsInternal) == sizeof(SsrsSolveStats), "stats layout");
 
 extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *fixed_mask,
                                     const double *fixed_values, const double *initial_guess,
@@ -493,7 +496,10 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
     SSRS_REQUIRE(conductivity && fixed_mask && fixed_values && potential && workspace,
                  "ssrs_potential_solve: NULL pointer");
     SSRS_REQUIRE(rows >= 3 && cols >= 3, "ssrs_potential_solve: need rows, cols >= 3");
-    SSRS_REQUIRE(workspace_bytes >= ssrs_potential_workspace_bytes(rows, cols),
+    // ssrs_potential_workspace_bytes is the bound that always suffices; a smaller workspace is
+    // accepted as long as the solver's own vectors fit, and the hierarchy reports "workspace
+    // exhausted" if it does not (it really takes ~840 B per cell)
+    SSRS_REQUIRE(workspace_bytes >= (sizeof(Scalars) + 255) / 256 * 256 + 10 * vec_bytes(static_cast<size_t>(rows) * cols) + 512,
                  "ssrs_potential_solve: workspace too small");
     SSRS_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0,
                  "ssrs_potential_solve: workspace must be 256-byte aligned");
@@ -530,12 +536,24 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
     amg.kdepth = (flags & SSRS_SOLVE_K_CYCLE) ? (((flags >> 12) & 15) ? ((flags >> 12) & 15) : 3) : 0;
     amg.symmetric = (flags & SSRS_SOLVE_ONE_SIDED) == 0;
     amg.strong_rounds = ((flags >> 8) & 15) ? ((flags >> 8) & 15) : 4;
+    float setup_ms = 0.f;
+    size_t ws_used = static_cast<size_t>(10 * vec_bytes(n)) + 512;
     if (use_amg) {
+        hipEvent_t s0, s1;
+        SSRS_HIP_CHECK(hipEventCreate(&s0));
+        SSRS_HIP_CHECK(hipEventCreate(&s1));
+        SSRS_HIP_CHECK(hipEventRecord(s0, st));
         char *amg_base = base + 10 * vec_bytes(n);
         amg_base = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(amg_base) + 255) / 256 * 256);
         const size_t amg_bytes = static_cast<size_t>(static_cast<char *>(workspace) + workspace_bytes - amg_base);
         const int rc = amg_setup(amg, conductivity, fixed_mask, rows, cols, amg_base, amg_bytes, st);
+        (void)hipEventRecord(s1, st);
+        (void)hipEventSynchronize(s1);
+        (void)hipEventElapsedTime(&setup_ms, s0, s1);
+        (void)hipEventDestroy(s0);
+        (void)hipEventDestroy(s1);
         if (rc != SSRS_OK) return rc;
+        ws_used += amg.workspace_used;
     }
     StencilArgs a{conductivity, use_amg ? amg.l0_rinv : nullptr, fixed_mask, rows, cols, use_amg ? 1 : 0, 1,
                   make_tile_walk(rows, cols)};
@@ -668,6 +686,8 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
         so->kernel_ms = ms;
         so->amg_levels = use_amg ? static_cast<int32_t>(amg.levels.size()) : 0;
         so->amg_coarsest = use_amg ? amg.levels.back().n : 0;
+        so->setup_ms = setup_ms;
+        so->workspace_used = ws_used;
     }
     return SSRS_OK;
 }

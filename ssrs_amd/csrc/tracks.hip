@@ -1277,6 +1277,14 @@ __host__ __device__ constexpr int thr_plane_shift(int rows, int cols)
     return sh;
 }
 
+// 1 / x to ~1e-16: hardware estimate + one Newton step (inf / NaN / 0 propagate as such)
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    const double r = __builtin_amdgcn_rcp(x);
+    const double c = r * (2.0 - x * r);
+    return (c - c == 0.0) ? c : r;            // keep the estimate's inf / NaN / 0 (x = 0, inf, NaN)
+}
+
 struct ThrPrior {
     float zero_t[8][2];      // thresholds of the masked prior after last move rc (scaled)
     uint32_t reversal;       // bit rc: the masked prior is all zero as well
@@ -1301,7 +1309,10 @@ __global__ __launch_bounds__(kBlock) void k_transition_thr(
         const size_t g = static_cast<size_t>(gr) * cols + gc;
         const double v = updraft[g];
         const double w = v != v ? v : (v > 1e-06 ? v : 1e-06);
-        s_inv[i] = 1.0 / w;
+        // the thresholds are rounded to f32 and guarded by a band of 1e-7: the weights need no
+        // correctly rounded divisions here (the exact sequence of the stepper has its own),
+        // a reciprocal with one Newton step (~1e-16) does
+        s_inv[i] = fast_rcp(w);
         s_pot[i] = potential ? potential[g] : 0.f;
     }
     __syncthreads();
@@ -1325,7 +1336,7 @@ __global__ __launch_bounds__(kBlock) void k_transition_thr(
 #pragma unroll
             for (int j = 0; j < 9; ++j) {
                 const int q = (lr + dr_of(j)) * LW + lc + dc_of(j);
-                double v = 2.0 / (ic + s_inv[q]);                      // harmonic mean
+                double v = 2.0 * fast_rcp(ic + s_inv[q]);               // harmonic mean
                 if (potential) {
                     const float d = pc - s_pot[q];
                     const float ninv = (j == 4) ? 0.f : ((j & 1) ? 1.f : SSRS_NINV_DIAG);
@@ -1350,8 +1361,7 @@ __global__ __launch_bounds__(kBlock) void k_transition_thr(
                     if ((pr.reversal >> rc) & 1u) t1 = t2 = __uint_as_float(kThrReversal);
                     else { t1 = pr.zero_t[rc][0]; t2 = pr.zero_t[rc][1]; }
                 } else {
-                    double r = __builtin_amdgcn_rcp(tot);
-                    r = r * (2.0 - tot * r);                             // one Newton step: ~1e-16
+                    const double r = fast_rcp(tot);
                     t1 = static_cast<float>(wa * r * static_cast<double>(kThrScale));
                     t2 = static_cast<float>(ab * r * static_cast<double>(kThrScale));
                     if (!(t2 <= kThrScale)) t1 = t2 = __uint_as_float(kThrPoison);   // tot overflowed

@@ -222,9 +222,11 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
     two_pass = bool(want_tracks) and not record
     if table is None and upd is not None:
         if use_table is None:
-            # building costs ~1 window evaluation per cell; pays once the batch
-            # takes more steps than that (>= ~rows steps per track)
-            use_table = n * rows >= 4 * rows * cols
+            # building the table is one streaming pass over the raster (0.5 ms at 5000 x 6000);
+            # a batch pays for it with its first few hundred thousand steps -- and tracks that
+            # wander in a basin of the potential take millions each (G11), so anything but a
+            # handful of tracks takes the table
+            use_table = n * max(rows, cols) >= rows * cols // 64 or n >= 4096
         if use_table:
             f32_ok = ring_table_applies(memory_parameter, scaling_parameter, two_pass,
                                         exact_only, steps_per_launch)

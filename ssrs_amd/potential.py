@@ -83,16 +83,27 @@ def solve_potential(updraft, move_dirn, rel_tol=1e-15, max_iterations=2000,
     vals = to_dev(vals_h)
     guess = to_dev(initial_guess, torch.float64)
     out = torch.empty((rows, cols), dtype=torch.float32, device=cond.device)
-    nbytes = nat.lib().ssrs_potential_workspace_bytes(rows, cols)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=cond.device)
+    # ssrs_potential_workspace_bytes is a safe upper bound (1.5 KB per cell: 45 GB at 5000 x 6000);
+    # the hierarchy really takes ~840 B per cell (tools/probe_solver_footprint.py), so the first
+    # try reserves 1.1 KB per cell and only a solve that runs out of it takes the full bound
+    full = nat.lib().ssrs_potential_workspace_bytes(rows, cols)
+    first = min(full, (1100 * rows * cols + (96 << 20)) // 256 * 256)
     stats = nat.SsrsSolveStats()
-    nat.check(nat.lib().ssrs_potential_solve(
-        nat.ptr(cond), nat.ptr(mask), nat.ptr(vals), nat.ptr(guess), nat.ptr(out),
-        rows, cols, C.c_double(rel_tol), int(max_iterations),
-        (0 if use_amg else nat.SSRS_SOLVE_NO_AMG) | (int(extra_sweeps) << 4) |
-        (2 if cycle == 'K' else 0) | (int(strong_rounds) << 8) | (int(kdepth) << 12) |
-        (4 if one_sided else 0), nat.ptr(ws),
-        C.c_size_t(nbytes), C.byref(stats), stream_ptr()))
+    flags = ((0 if use_amg else nat.SSRS_SOLVE_NO_AMG) | (int(extra_sweeps) << 4) |
+             (2 if cycle == 'K' else 0) | (int(strong_rounds) << 8) | (int(kdepth) << 12) |
+             (4 if one_sided else 0))
+    for nbytes in ((first, full) if first < full else (full,)):
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=cond.device)
+        rc = nat.lib().ssrs_potential_solve(
+            nat.ptr(cond), nat.ptr(mask), nat.ptr(vals), nat.ptr(guess), nat.ptr(out),
+            rows, cols, C.c_double(rel_tol), int(max_iterations), flags, nat.ptr(ws),
+            C.c_size_t(nbytes), C.byref(stats), stream_ptr())
+        if rc == nat.SSRS_ERR_INVALID and nbytes < full and \
+                b'workspace' in nat.lib().ssrs_last_error():
+            del ws
+            continue
+        nat.check(rc)
+        break
     if not stats.converged:
         import warnings
         warnings.warn(f'potential solve stopped at |r|/|b| = {stats.residual:.3e} after '
@@ -101,5 +112,7 @@ def solve_potential(updraft, move_dirn, rel_tol=1e-15, max_iterations=2000,
     if return_stats:
         return res, dict(iterations=int(stats.iterations), converged=bool(stats.converged),
                          residual=float(stats.residual), kernel_ms=float(stats.kernel_ms),
-                         amg_levels=int(stats.amg_levels), amg_coarsest=int(stats.amg_coarsest))
+                         amg_levels=int(stats.amg_levels), amg_coarsest=int(stats.amg_coarsest),
+                         setup_ms=float(stats.setup_ms), workspace_used=int(stats.workspace_used),
+                         workspace_bytes=int(nbytes))
     return res

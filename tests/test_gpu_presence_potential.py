@@ -137,3 +137,28 @@ def test_potential_two_phase_raster_iteration_budget(gpu):
                                   cycle='K', kdepth=3)
     assert st_k['converged'], st_k
     np.testing.assert_allclose(pot_k.cpu().numpy(), p, rtol=0, atol=2e-3)
+
+
+def test_potential_workspace_tight_first_try_and_exhaustion(gpu, golden):
+    """The size query is an upper bound (1.5 KB per cell); the host side first reserves 1.1 KB per
+    cell (the hierarchy takes ~840 B).  A workspace that really is too small must fail loudly, not
+    corrupt memory."""
+    import ctypes as C
+    from ssrs_amd import layers, _native as nat
+    from ssrs_amd.potential import solve_potential, dirichlet_rasters
+    from ssrs_amd._device import to_dev, stream_ptr
+    g = golden('g8_c1.npz')
+    upd = layers.get_above_threshold_speed(g['orograph_f32'], 0.75)
+    pot, st = solve_potential(upd, 0., rel_tol=1e-10, return_stats=True)
+    assert st['converged'] and 0 < st['workspace_used'] <= st['workspace_bytes']
+    assert st['workspace_bytes'] < nat.lib().ssrs_potential_workspace_bytes(500, 600)
+    assert 500 < st['workspace_used'] / (500 * 600) < 1100, st
+    cond = to_dev(upd, torch.float64)
+    mask_h, vals_h = dirichlet_rasters(0., (500, 600))
+    mask, vals = to_dev(mask_h), to_dev(vals_h)
+    out = torch.empty((500, 600), dtype=torch.float32, device='cuda')
+    small = 10 * 8 * 500 * 600 + (8 << 20)                       # the solver's vectors + a sliver
+    ws = torch.empty(small, dtype=torch.uint8, device='cuda')
+    rc = nat.lib().ssrs_potential_solve(nat.ptr(cond), nat.ptr(mask), nat.ptr(vals), None, nat.ptr(out), 500, 600,
+                                        C.c_double(1e-10), 100, 0, nat.ptr(ws), C.c_size_t(small), None, stream_ptr())
+    assert rc == nat.SSRS_ERR_INVALID and b'workspace' in nat.lib().ssrs_last_error()
