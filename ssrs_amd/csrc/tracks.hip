@@ -2489,7 +2489,12 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                 a.hist_copies = copies_ptr;
                 a.ncopies = ncopies;
             }
-            if (binning_on || tiles_on) a.visits = ws.visits;
+            // the first-move launch is one iteration deep: its visits go straight to the histogram
+            // (one binning block for the whole batch took 170 us); generic kernel, plain keys
+            const bool bin_window = binning_on && !first_move, bin_tiles = tiles_on && !first_move;
+            const uint32_t keep_r = a.vis_r, keep_c = a.vis_c;
+            if (first_move) { a.vis_r = static_cast<uint32_t>(p->cols); a.vis_c = 1u; }
+            if (bin_window || bin_tiles) a.visits = ws.visits;
             a.visit_stride = ws.visit_stride;
             a.vcap = ws.cap;
             const uint32_t *rec_counts = nullptr;
@@ -2512,7 +2517,7 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                     ch.vcap = vcap;
                     ch.cap = ws.cap;
                     ch.steps = Sl;
-                    ch.transposed = (hist_t && binning_on) ? 1 : 0;
+                    ch.transposed = (hist_t && bin_window) ? 1 : 0;
                     hipError_t e1 = hipMemcpyAsync(base, ws.ctl->count[launch & 3], kXcd * sizeof(uint32_t),
                                                    hipMemcpyDeviceToDevice, st);
                     hipError_t e2 = identity ? hipSuccess
@@ -2557,7 +2562,7 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                 hipEvent_t e;
                 if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); ev_bin.push_back(e); }
             }
-            if (binning_on) {
+            if (bin_window) {
                 ++window_launches;
                 hipEvent_t b0 = nullptr, b1 = nullptr;
                 if (profile && hipEventCreate(&b0) == hipSuccess) (void)hipEventRecord(b0, st);
@@ -2573,7 +2578,7 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                     ev_hist.push_back(b1);
                 }
             }
-            if (tiles_on) {
+            if (bin_tiles) {
                 ++tile_launches;
                 hipEvent_t b0 = nullptr, b1 = nullptr;
                 if (profile && hipEventCreate(&b0) == hipSuccess) (void)hipEventRecord(b0, st);
@@ -2600,9 +2605,11 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                     ev_hist.push_back(b1);
                 }
             }
-            if (rec_counts && hist && !binning_on && !tiles_on)      // recorded launch outside both binning paths
+            if (rec_counts && hist && !bin_window && !bin_tiles)      // recorded launch outside both binning paths
                 hipLaunchKernelGGL(k_count_visits, dim3(blocks), dim3(kBlock), 0, st, a.visits, a.vcap, Sl, rec_counts, hist,
                                    static_cast<uint32_t>(ncell));
+            a.vis_r = keep_r;
+            a.vis_c = keep_c;
             if (hipGetLastError() != hipSuccess) { rc = set_error(SSRS_ERR_HIP, "stepper launch failed"); break; }
         }
         if (rc != SSRS_OK) break;

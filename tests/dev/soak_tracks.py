@@ -47,7 +47,19 @@ while time.time() - t0 < budget:
     variants = [dict(use_table=True, ring=False), dict(use_table=True, ring=False, scattered=True), dict(use_table=False)]
     if mem == 1 and spl % 2 == 0:
         variants += [dict(use_table=True, ring=True), dict(use_table=True, ring=True, scattered=True),
-                     dict(use_table=True, ring=True, schedule=False), dict(use_table=True, ring=True, binning=False)]
+                     dict(use_table=True, ring=True, schedule=False), dict(use_table=True, ring=True, binning=False),
+                     dict(use_table=True, thr=True), dict(use_table=True, thr=True, scattered=True),
+                     dict(use_table=True, thr=True, schedule=False), dict(use_table=True, thr=True, binning=False)]
+    check_traj = rng.random() < 0.15 and int(ref['steps']) < 3e6
+    if check_traj:                                            # recorded trajectories, any path
+        full = c_oracle.simulate_tracks(dirn, starts, (rows, cols), mem, 1., upd, pot, seed=s)
+        kw = dict(variants[int(rng.integers(0, len(variants)))])
+        res = movmodel.simulate_tracks(dirn, starts, (rows, cols), mem, 1., upd, pot, seed=s, steps_per_launch=spl,
+                                       want_tracks=True, **kw)
+        if not (np.array_equal(res.traj.cpu().numpy(), np.concatenate(full['tracks'])) and
+                np.array_equal(res.hist.cpu().numpy().view(np.uint32), ref['hist'])):
+            print('TRAJECTORY MISMATCH', dict(seed=seed, rows=rows, cols=cols, n=n, dirn=dirn, kind=kind, spl=spl, mem=mem), kw, flush=True)
+            sys.exit(1)
     for kw in variants:
         res = movmodel.simulate_tracks(dirn, starts, (rows, cols), mem, 1., upd, pot, seed=s, steps_per_launch=spl, **kw)
         ok = (np.array_equal(res.lengths.cpu().numpy(), ref['lengths']) and
@@ -59,4 +71,4 @@ while time.time() - t0 < budget:
     n_case += 1; n_steps += int(ref['steps'])
     if n_case % 20 == 0:
         print(f'{n_case} cases, {n_steps:.3e} oracle steps, {time.time() - t0:.0f} s', flush=True)
-print(f'soak ok: {n_case} cases x 3-7 GPU variants, {n_steps:.3e} steps each', flush=True)
+print(f'soak ok: {n_case} cases x 3-11 GPU variants, {n_steps:.3e} steps each', flush=True)

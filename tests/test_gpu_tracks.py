@@ -616,6 +616,10 @@ def test_wandering_batches_move_from_the_window_to_tile_buckets(gpu, dirn):
     (30., 9000, dict(use_table=True, memory=3)),            # generic table kernel
     (0., 9000, dict(use_table=True, ring=True, schedule=False)),   # identity first list
     (0., 9000, dict(use_table=True, ring=True, steps_per_launch=34)),
+    (0., 9000, dict(use_table=True, thr=True)),             # threshold stepper: row window
+    (270., 9000, dict(use_table=True, thr=True)),           # ... transposed keys (first move plain)
+    (135., 9000, dict(use_table=True, thr=True)),           # ... tile buckets
+    (20., 600, dict(use_table=True, thr=True, schedule=False)),
 ])
 def test_recorded_trajectories_equal_the_oracle(gpu, dirn, n, kw):
     from ssrs_amd import movmodel
