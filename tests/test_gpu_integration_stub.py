@@ -55,10 +55,10 @@ def test_integration_md_stub_runs_and_matches_oracle(gpu):
     ok(lib.ssrs_track_params_init(C.byref(prm), rows, cols, track_dirn_restrict, C.c_double(track_stochastic_nu)))
     prm.prior[:] = [float(v) for v in orc.get_directional_probs(track_direction * np.pi / 180.)]
     upd, pot = dev(updraft, torch.float64), dev(potential, torch.float32)
-    lib.ssrs_transition_ring_bytes.restype = C.c_size_t
-    table = torch.empty(lib.ssrs_transition_ring_bytes(rows, cols) // 4, dtype=torch.float32, device='cuda')
-    ok(lib.ssrs_transition_ring_build(p(upd), p(pot), p(table), rows, cols, STREAM()))
-    prm.flags |= 16                                         # SSRS_TRACKS_RING_TABLE
+    lib.ssrs_transition_thr_bytes.restype = C.c_size_t
+    table = torch.empty(lib.ssrs_transition_thr_bytes(rows, cols) // 4, dtype=torch.float32, device='cuda')
+    ok(lib.ssrs_transition_thr_build(p(upd), p(pot), prm.prior, p(table), rows, cols, STREAM()))
+    prm.flags |= 128                                        # SSRS_TRACKS_THR_TABLE
     starts = dev(np.stack([starting_rows, starting_cols], 1), torch.int32)
     n = len(starting_rows)
     lib.ssrs_tracks_workspace_bytes.restype = C.c_size_t
@@ -67,25 +67,40 @@ def test_integration_md_stub_runs_and_matches_oracle(gpu):
     hist = torch.zeros((rows, cols), dtype=torch.int32, device='cuda')
     lengths = torch.empty(n, dtype=torch.int32, device='cuda')
     ends = torch.empty((n, 2), dtype=torch.int16, device='cuda')
-    ok(lib.ssrs_tracks_simulate(C.byref(prm), p(upd), p(pot), p(table), p(starts), C.c_int64(n),
-                                C.c_uint64(sim_seed + real_id), C.c_uint64(0),
-                                p(hist), p(ends), p(lengths), None, None,
-                                p(ws), C.c_size_t(nb), None, STREAM()))
+    pool = torch.empty(256 << 20, dtype=torch.uint8, device='cuda')     # recorded visits: 4 B per step and slot
+    lib.ssrs_traj_recorder_create.restype = C.c_void_p
+    rec = C.c_void_p(lib.ssrs_traj_recorder_create(p(pool), C.c_size_t(pool.numel())))
+    ok(lib.ssrs_tracks_simulate_rec(C.byref(prm), p(upd), p(pot), p(table), p(starts), C.c_int64(n),
+                                    C.c_uint64(sim_seed + real_id), C.c_uint64(0),   # seed, first global track id
+                                    p(hist), p(ends), p(lengths), rec,
+                                    p(ws), C.c_size_t(nb), None, STREAM()))
+    assert lib.ssrs_traj_recorder_complete(rec)             # else: a larger pool, or the two-call form
+    offsets = torch.zeros(n + 1, dtype=torch.int64, device='cuda')
+    torch.cumsum(lengths, 0, out=offsets[1:])
+    traj = torch.empty((int(offsets[-1]), 2), dtype=torch.int16, device='cuda')
+    cursor = torch.empty(n, dtype=torch.int32, device='cuda')
+    ok(lib.ssrs_tracks_gather(rec, p(starts), C.c_int64(n), p(offsets), p(traj), p(cursor), C.c_size_t(4 * n), STREAM()))
+    torch.cuda.synchronize()
+    lib.ssrs_traj_recorder_destroy(rec)
+    off = offsets.cpu().numpy()
+    tracks = [traj.cpu().numpy()[off[i]:off[i + 1]] for i in range(n)]      # the list simulator.py:382-385 pickles
 
     # ---- the oracle on the same inputs and streams
     ref = c_oracle.simulate_tracks(track_direction, np.stack([starting_rows, starting_cols], 1), (rows, cols),
                                    track_dirn_restrict, track_stochastic_nu, updraft, potential,
-                                   seed=sim_seed + real_id, want_traj=False)
+                                   seed=sim_seed + real_id, want_traj=True)
     assert np.array_equal(lengths.cpu().numpy(), ref['lengths'])
     assert np.array_equal(ends.cpu().numpy(), ref['ends'])
     assert np.array_equal(hist.cpu().numpy().view(np.uint32), ref['hist'])
+    for a, b in zip(tracks, ref['tracks']):
+        assert np.array_equal(a, b)
 
     # bad arguments come back as codes + message, not as crashes
     prm.memory_parameter = 3
     rc = lib.ssrs_tracks_simulate(C.byref(prm), p(upd), p(pot), p(table), p(starts), C.c_int64(n),
                                   C.c_uint64(1), C.c_uint64(0), p(hist), p(ends), p(lengths), None, None,
                                   p(ws), C.c_size_t(nb), None, STREAM())
-    assert rc != 0 and b'RING_TABLE' in lib.ssrs_last_error()
+    assert rc != 0 and b'THR_TABLE' in lib.ssrs_last_error()
 
 
 def test_hist_reduce_through_the_c_abi_with_a_callers_rccl_communicator(gpu):
