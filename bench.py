@@ -343,8 +343,8 @@ def main():
     kernel_s = acc['step_kernel_ms'] / 1e3
     # bytes the chosen data path really requests per step (read + 4 B visit / histogram update)
     # (window gathers 18 x 4 + 4; f64 table row 64 + 24 + 4; f64 three candidates 24 + 4; ring triple
-    # 12 + 4; threshold pair 8 + 4)
-    moved_bytes = 76 if args.direct else (92 if args.exact_only else (28 if args.f64_table else (16 if args.ring_table else 12)))
+    # 12 + 4; threshold dword 4 + 4)
+    moved_bytes = 76 if args.direct else (92 if args.exact_only else (28 if args.f64_table else (16 if args.ring_table else 8)))
     achieved = acc['steps'] * STEP_BYTES / kernel_s / 1e9 if kernel_s > 0 else 0.0
     moved_gbps = acc['steps'] * moved_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0
     raster_s = acc['raster_ms'] / 1e3 / K
@@ -371,7 +371,7 @@ def main():
             'stepper_path': ('direct 3x3 gathers' if args.direct else
                              ('f64 transition table' if (args.f64_table or args.exact_only)
                               else ('f32 ring table, exact fallback on the raw windows' if args.ring_table else
-                                    'f32 threshold table (two decision thresholds per cell and last move), '
+                                    'threshold table (two 16-bit decision thresholds per cell and last move), '
                                     'exact fallback on the raw windows'))),
             'potential': pot_label,
         },
@@ -390,10 +390,10 @@ def main():
             'kernel': ('k_step_tracks' if (args.direct or args.f64_table or args.exact_only)
                        else ('k_step_lean<ring>' if args.ring_table else 'k_step_thr')) + ' (K2 stepper, rank 0)',
             # what bounds it: the dependent chain of one step (see dependent_chain below and
-            # profiles/r02_stepper_chain.md), not HBM: the kernel moves 16 B per step
+            # profiles/r02_stepper_chain.md), not HBM: the kernel moves 8 B per step
             'bound': 'latency',
-            # achieved = bytes the shipped data path really requests per step (one 12-byte triple of
-            # the f32 ring table + the 4-byte visit) x steps / sum of the stepper launch durations
+            # achieved = bytes the shipped data path really requests per step (the 4-byte
+            # threshold entry + the 4-byte visit) x steps / sum of the stepper launch durations
             'achieved': moved_gbps, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
             'frac': moved_gbps / HBM_PEAK_GBPS,
             'traffic': None,

@@ -171,8 +171,8 @@ typedef struct SsrsTrackParams {
                                       per-step window to tile buckets and only then to this
                                       variant; small ones directly.  Results are identical */
 #define SSRS_TRACKS_NO_SCATTERED 64 /* never switch to that variant (A/B) */
-#define SSRS_TRACKS_THR_TABLE 128   /* `table` is the threshold table of ssrs_transition_thr_build (one aligned
-                                      8-byte gather and two comparisons per step); needs updraft (+ potential
+#define SSRS_TRACKS_THR_TABLE 128   /* `table` is the threshold table of ssrs_transition_thr_build (one 4-byte
+                                      gather and two comparisons per step); needs updraft (+ potential
                                       if the table was built with it) for the exact decision of near-ties,
                                       memory_parameter 1, scaling_parameter 1, traj NULL, even steps_per_launch,
                                       and params->prior equal to the prior the table was built with */
@@ -217,14 +217,16 @@ int ssrs_transition_ring_build(const double *updraft, const float *potential, fl
                                int rows, int cols, void *stream);
 
 /* The decision thresholds themselves (SSRS_TRACKS_THR_TABLE): for every cell and every last move
- * rc (ring position 0..7) the two f32 numbers 2^24 a / (a + b + c), 2^24 (a + b) / (a + b + c), with
- * a, b, c the three admissible weights of movmodel.py:292-309 in ascending neighbour index -- the
- * boundaries np.random.choice's inverse-cdf pick compares the uniform with.  A row whose weights are
- * all zero carries the masked prior's thresholds (movmodel.py:234-238); boundary cells, poisoned rows
- * and rows where the unmasked prior decides are NaN-coded flags.  Eight planes (one per last move)
- * of 8-byte entries at a power-of-two stride, ssrs_transition_thr_bytes(rows, cols) bytes in all,
- * 64-byte aligned; the table belongs to one heading (`prior` [host], 9 doubles =
- * SsrsTrackParams.prior).  rows * cols <= 2^26. */
+ * rc (ring position 0..7) one dword T1 | T2 << 16 with T1 = round(2^16 a / (a + b + c)), T2 =
+ * round(2^16 (a + b) / (a + b + c)) (clamped to 65535), a, b, c the three admissible weights of
+ * movmodel.py:292-309 in ascending neighbour index -- the boundaries np.random.choice's inverse-cdf
+ * pick compares the uniform with; the stepper decides on the uniform's top 16 bits and hands a
+ * uniform within one unit of a boundary (3e-5 per boundary) to the exact sequence.  A row whose
+ * weights are all zero carries the masked prior's thresholds (movmodel.py:234-238); boundary cells,
+ * poisoned rows and rows where the unmasked prior decides are flag entries (T1 = 0xFFFF > T2 = code).
+ * Eight planes (one per last move) of 4-byte entries at a power-of-two stride,
+ * ssrs_transition_thr_bytes(rows, cols) bytes in all, 64-byte aligned; the table belongs to one
+ * heading (`prior` [host], 9 doubles = SsrsTrackParams.prior).  rows * cols <= 2^27. */
 size_t ssrs_transition_thr_bytes(int rows, int cols);
 int ssrs_transition_thr_build(const double *updraft, const float *potential, const double *prior,
                               float *thr, int rows, int cols, void *stream);

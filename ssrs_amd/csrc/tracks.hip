@@ -1246,32 +1246,38 @@ __device__ __forceinline__ void split_cell(uint32_t c, uint32_t cols, double inv
 // bound by its instruction COUNT, not by Philox (hidden under the gather) nor by HBM.  The
 // threshold table moves everything that depends on the cell and the last move only -- picking
 // the three admissible weights, ordering them by k, summing, normalising -- into the table
-// builder.  Per (cell, last move rc) the table holds the two decision thresholds themselves,
-//     T1 = 2^24 a / (a + b + c),   T2 = 2^24 (a + b) / (a + b + c)       (f32, a b c in ascending k)
-// and a step is: one aligned 8-byte gather, two subtractions from the top 24 bits of the
-// uniform, two sign bits -> the chosen cell.  |T - 2^24 cdf_k/cdf_8| <= 0.5 (f32 rounding; the
-// f64 quotient differs from the reference's normalise-twice sequence by 1e-15) and the top-24-bit
-// uniform is within [0, 1) of 2^24 u, so whenever both |ufi - T| > 2 the decision is the
-// reference's; inside that band (2.4e-7 per boundary) the exact sequence on the raw windows
-// decides.  Everything irregular is a flag in the entry (a NaN, so the band test catches it):
-//   boundary cell      (k > burnin: the track ends; else the burn-in nudge: exact sequence)
-//   poisoned row       (a NaN / infinite weight: exact sequence, movmodel.py:228-230)
-//   reversal           (the three weights AND the masked prior are all zero: the unmasked prior
+// builder.  Per (cell, last move rc) the table holds the two decision thresholds themselves as
+// 16-bit fixed point in one dword,
+//     T1 = round(2^16 a / (a + b + c)),   T2 = round(2^16 (a + b) / (a + b + c))   (a b c in ascending k,
+//     both clamped to 65535)
+// and a step is: one 4-byte gather, two integer subtractions from the top 16 bits of the uniform,
+// two sign bits -> the chosen cell.  |T - 2^16 cdf_k/cdf_8| <= 0.5 (rounding; the f64 quotient
+// differs from the reference's normalise-twice sequence by 1e-15; the clamp only matters where
+// the uniform's top bits are 65534 / 65535, which the band covers) and the uniform's top 16 bits
+// ufi satisfy ufi <= 2^16 u < ufi + 1, so ufi - T >= 1 means cdf_k/cdf_8 <= u and ufi - T <= -2
+// means it is not: the decision is the reference's unless ufi - T is -1 or 0 (3e-5 per boundary),
+// where the exact sequence on the raw windows decides.  Everything irregular is an entry with
+// T1 > T2 (impossible otherwise): T1 = 0xFFFF and T2 =
+//   0  poisoned row    (a NaN / infinite weight: exact sequence, movmodel.py:228-230)
+//   1  boundary cell   (k > burnin: the track ends; else the burn-in nudge: exact sequence)
+//   2  reversal        (the three weights AND the masked prior are all zero: the unmasked prior
 //                       decides among its own cells, movmodel.py:239-240: thresholds thr9)
 // A row whose three weights are zero while the masked prior is not carries the PRIOR's two
-// thresholds (movmodel.py:234-238), so the common fallback needs no branch at all.  The sign
-// bit of T1 marks the cells the burn-in nudge moves (row 1, rows - 2, col cols - 2).
+// thresholds (movmodel.py:234-238), so the common fallback needs no branch at all.  The cells the
+// burn-in nudge moves (rows <= 1, >= rows - 2, cols >= cols - 2) are recognised from the cell
+// index while some lane of the wave is in its burn-in (a separate phase of the loop).
 // The first move of a track (eight admissible cells) is made by one iteration of the generic
 // kernel before the first launch of this one.
-constexpr uint32_t kThrPoison = 0x7FC00000u, kThrBoundary = 0x7FC00001u, kThrReversal = 0x7FC00002u;
-constexpr float kThrScale = 16777216.0f;      // 2^24
-constexpr float kThrBand = 2.0f;
+// Eight planes (one per last move) of 4-byte entries: neighbouring tracks gather from the same
+// few cache lines (32 cells per 128-byte line), which is what the CU's address unit charges for.
+constexpr uint32_t kThrPoison = 0x0000FFFFu, kThrBoundary = 0x0001FFFFu, kThrReversal = 0x0002FFFFu;
+constexpr double kThrScale = 65536.0;
 
-// The table is eight planes (one per last move rc) of 8-byte entries, plane p at byte offset
+// The table is eight planes (one per last move rc) of 4-byte entries, plane p at byte offset
 // p << thr_plane_shift: a power-of-two stride makes a step's address one shift-or
 __host__ __device__ constexpr int thr_plane_shift(int rows, int cols)
 {
-    const unsigned long long bytes = static_cast<unsigned long long>(rows) * static_cast<unsigned long long>(cols) * 8ull;
+    const unsigned long long bytes = static_cast<unsigned long long>(rows) * static_cast<unsigned long long>(cols) * 4ull;
     int sh = 8;
     while ((1ull << sh) < bytes) ++sh;
     return sh;
@@ -1285,15 +1291,24 @@ __device__ __forceinline__ double fast_rcp(double x)
     return (c - c == 0.0) ? c : r;            // keep the estimate's inf / NaN / 0 (x = 0, inf, NaN)
 }
 
+__host__ __device__ __forceinline__ uint32_t thr_pack(double b1, double b2)
+{   // two boundaries in [0, 1] -> T1 | T2 << 16
+    double t1 = b1 * kThrScale + 0.5, t2 = b2 * kThrScale + 0.5;      // round half up (values >= 0)
+    uint32_t u1 = t1 >= 65535.0 ? 65535u : static_cast<uint32_t>(t1);
+    uint32_t u2 = t2 >= 65535.0 ? 65535u : static_cast<uint32_t>(t2);
+    if (u1 > u2) u1 = u2;                                              // b1 <= b2 up to rounding
+    return u1 | (u2 << 16);
+}
+
 struct ThrPrior {
-    float zero_t[8][2];      // thresholds of the masked prior after last move rc (scaled)
+    uint32_t zero_e[8];      // entry of the masked prior after last move rc
     uint32_t reversal;       // bit rc: the masked prior is all zero as well
-    float thr9[9];           // thresholds of the unmasked prior (scaled), k = 0..8
+    uint32_t thr9[9];        // thresholds of the unmasked prior (2^16 units, clamped), k = 0..8
 };
 
 __global__ __launch_bounds__(kBlock) void k_transition_thr(
     const double *__restrict__ updraft, const float *__restrict__ potential,
-    float *__restrict__ table_out, int rows, int cols, int tiles_x, int ntiles, const ThrPrior pr, int plane_shift)
+    uint32_t *__restrict__ table_out, int rows, int cols, int tiles_x, int ntiles, const ThrPrior pr, int plane_shift)
 {
     // staging as k_transition_table: clipped reciprocals and potential of the tile + halo
     constexpr int LW = kTabW + 2, LH = kTabH + 2;
@@ -1324,10 +1339,10 @@ __global__ __launch_bounds__(kBlock) void k_transition_thr(
         if (row >= rows) break;
         const size_t i = static_cast<size_t>(row) * cols + col;
         const bool interior = row > 0 && col > 0 && row < rows - 1 && col < cols - 1;
-        float o[16];
+        uint32_t o[8];
         if (!interior) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) o[j] = __uint_as_float(kThrBoundary);
+            for (int j = 0; j < 8; ++j) o[j] = kThrBoundary;
         } else {
             double w[9];
             const double ic = s_inv[lr * LW + lc];
@@ -1346,7 +1361,6 @@ __global__ __launch_bounds__(kBlock) void k_transition_thr(
                 bad |= (v - v != 0.0);                                  // inf or NaN (also the centre's)
                 w[j] = v > 0.0 ? v : 0.0;                               // clip(min=0)
             }
-            const bool zone = row == 1 || row == rows - 2 || col == cols - 2;
 #pragma unroll
             for (int rc = 0; rc < 8; ++rc) {
                 const uint32_t ord = ring_order(rc);
@@ -1354,29 +1368,23 @@ __global__ __launch_bounds__(kBlock) void k_transition_thr(
                 const double wa = w[kRingK[ring3[ord & 3u]]], wb = w[kRingK[ring3[(ord >> 2) & 3u]]],
                              wc = w[kRingK[ring3[(ord >> 4) & 3u]]];
                 const double ab = wa + wb, tot = ab + wc;               // np.cumsum's order
-                float t1, t2;
+                uint32_t e;
                 if (bad) {
-                    t1 = t2 = __uint_as_float(kThrPoison);
+                    e = kThrPoison;
                 } else if (!(tot > 0.0)) {
-                    if ((pr.reversal >> rc) & 1u) t1 = t2 = __uint_as_float(kThrReversal);
-                    else { t1 = pr.zero_t[rc][0]; t2 = pr.zero_t[rc][1]; }
+                    e = ((pr.reversal >> rc) & 1u) ? kThrReversal : pr.zero_e[rc];
                 } else {
                     const double r = fast_rcp(tot);
-                    t1 = static_cast<float>(wa * r * static_cast<double>(kThrScale));
-                    t2 = static_cast<float>(ab * r * static_cast<double>(kThrScale));
-                    if (!(t2 <= kThrScale)) t1 = t2 = __uint_as_float(kThrPoison);   // tot overflowed
+                    const double b1 = wa * r, b2 = ab * r;
+                    e = (b2 <= 1.0000001) ? thr_pack(b1, b2) : kThrPoison;       // tot overflowed: NaN / inf
                 }
-                if (zone) t1 = __uint_as_float(__float_as_uint(t1) | 0x80000000u);
-                o[2 * rc] = t1;
-                o[2 * rc + 1] = t2;
+                o[rc] = e;
             }
         }
-        // plane rc holds the entries of last move rc for all cells, 8 bytes each: neighbouring
-        // tracks (neighbouring lanes) then gather from the same few cache lines
+        // plane rc holds the entries of last move rc for all cells, 4 bytes each
 #pragma unroll
         for (int rc = 0; rc < 8; ++rc)
-            *reinterpret_cast<float2 *>(reinterpret_cast<char *>(table_out) + (static_cast<size_t>(rc) << plane_shift) + i * 8) =
-                make_float2(o[2 * rc], o[2 * rc + 1]);
+            *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(table_out) + (static_cast<size_t>(rc) << plane_shift) + i * 4) = o[rc];
     }
 }
 
@@ -1434,7 +1442,10 @@ __global__ __launch_bounds__(kBlock) void k_step_thr(const StepArgs a, const Thr
     }
     wave_burn = __builtin_amdgcn_readfirstlane(wave_burn);
     const uint32_t psh = static_cast<uint32_t>(a.plane_shift);
-    uint2 e = *reinterpret_cast<const uint2 *>(tab + ((rc << psh) | (cell << 3)));
+    uint32_t e = *reinterpret_cast<const uint32_t *>(tab + ((rc << psh) | (cell << 2)));
+    // column of the cell, kept up to date only while the burn-in phase of the loop runs
+    uint32_t colv = static_cast<uint32_t>(s.pos >> 16) & 0xFFFFu;
+    const uint32_t zone_lo = 2u * ucols, zone_hi = (urows - 2u) * ucols, zone_col = ucols - 2u;
     uint32_t *vrow = (HM == 1 || HM == 2) ? a.visits + iv : nullptr;              // this lane's slot, row `it`
     uint32_t *hbase = a.hist;
     if (HM == 3 && a.hist_copies)
@@ -1451,36 +1462,38 @@ __global__ __launch_bounds__(kBlock) void k_step_thr(const StepArgs a, const Thr
         } else {
             w0 = pend_a; w1 = pend_b;
         }
-        const float ufi = static_cast<float>(w0 >> 8);               // top 24 bits of u, exact
-        const float d1 = ufi - __uint_as_float(e.x & 0x7FFFFFFFu), d2 = ufi - __uint_as_float(e.y);
-        float m;                                                     // min(|d1|, |d2|); NaN entries (flags) give NaN
-        asm("v_min_f32 %0, |%1|, |%2|" : "=v"(m) : "v"(d1), "v"(d2));
-        bool special = !(m > kThrBand);
-        if (burn) special = special | ((static_cast<int32_t>(e.x) < 0) & (it <= it_burn));
+        const uint32_t ufi = w0 >> 16;                               // top 16 bits of u
+        const int32_t d1 = static_cast<int32_t>(ufi) - static_cast<int32_t>(e & 0xFFFFu);
+        const int32_t d2 = static_cast<int32_t>(ufi) - static_cast<int32_t>(e >> 16);
+        // ufi - T in {-1, 0}: the uniform is within rounding of a boundary; T1 > T2 (d1 < d2): a flag entry
+        bool special = (static_cast<uint32_t>(d1 + 1) < 2u) | (static_cast<uint32_t>(d2 + 1) < 2u) | (d1 < d2);
+        if (burn) {
+            const bool zone = (cell < zone_lo) | (cell >= zone_hi) | (colv >= zone_col);
+            special = special | (zone & (it <= it_burn));
+        }
         special = special & (stm != 0u);
         const uint32_t ord = static_cast<uint32_t>(kRingOrder >> __umul24(6u, rc)) & 63u;
-        const uint32_t neg = (__float_as_uint(d1) >> 31) + (__float_as_uint(d2) >> 31);     // 2 - sel
+        const uint32_t neg = (static_cast<uint32_t>(d1) >> 31) + (static_cast<uint32_t>(d2) >> 31);     // 2 - sel
         uint32_t nc = (rc + 7u + ((ord >> (4u - 2u * neg)) & 3u)) & 7u;
-        uint32_t base = cell;
+        uint32_t base = cell, base_col = colv;
+        const uint32_t cell_before = cell;
         uint32_t go = stm;
         if (__builtin_expect(__any(special), 0)) {
             if (special) {
-                const uint32_t t1b = e.x;
-                const bool zone = static_cast<int32_t>(t1b) < 0 && k <= a.burnin;
                 bool exact = true;
-                if (t1b == kThrBoundary && k > a.burnin) {
+                if (e == kThrBoundary && k > a.burnin) {
                     go = 0u;                                           // movmodel.py:286-288: the track ends here
                     span = 0u;
                     exact = false;
-                } else if (t1b == kThrReversal && !zone) {
+                } else if (e == kThrReversal && k > a.burnin) {
                     // unmasked prior (movmodel.py:239-240): count of thresholds <= u
                     int idx = 0;
                     bool near = false;
 #pragma unroll
                     for (int q = 0; q < 9; ++q) {
-                        const float d = ufi - pr.thr9[q];
-                        idx += d >= 0.f ? 1 : 0;
-                        near |= !(fabsf(d) > kThrBand);
+                        const int32_t d = static_cast<int32_t>(ufi) - static_cast<int32_t>(pr.thr9[q]);
+                        idx += d >= 0 ? 1 : 0;
+                        near |= static_cast<uint32_t>(d + 1) < 2u;
                     }
                     const uint32_t pnc = static_cast<uint32_t>(kRingOfK >> (4 * (idx > 8 ? 4 : idx))) & 0xFu;
                     if (!near && pnc < 8u) { nc = pnc; exact = false; }
@@ -1505,6 +1518,7 @@ __global__ __launch_bounds__(kBlock) void k_step_thr(const StepArgs a, const Thr
                     const int idx = choose_move(w, prr, 1.0, restriction_of(last), words_to_uniform(w0, w1), false);
                     nc = static_cast<uint32_t>(kRingOfK >> (4 * idx)) & 0xFu;
                     base = __umul24(static_cast<uint32_t>(er), ucols) + static_cast<uint32_t>(ec);
+                    base_col = static_cast<uint32_t>(ec);
                 }
             }
         }
@@ -1514,7 +1528,12 @@ __global__ __launch_bounds__(kBlock) void k_step_thr(const StepArgs a, const Thr
         cell = (moved_to & go) | (cell & ~go);
         rc = (nc & go) | (rc & ~go);
         k -= static_cast<int>(go);                                    // go is 0 or -1
-        e = *reinterpret_cast<const uint2 *>(tab + ((rc << psh) | (cell << 3)));
+        if (burn) {
+            // column of the new cell (the exact path may have moved the base: recompute there)
+            const uint32_t moved_col = base == cell_before ? colv + dc - 1u : base_col + dc - 1u;
+            colv = (moved_col & go) | (colv & ~go);
+        }
+        e = *reinterpret_cast<const uint32_t *>(tab + ((rc << psh) | (cell << 2)));
         // ---- presence histogram (see k_step_tracks)
         if (HM == 1) {
             *vrow = cell | ~go;                                       // idle: 0xFFFFFFFF
@@ -2166,13 +2185,12 @@ static void prior_tables(const double *prior, ThrPrior *out)
         const uint32_t ord = ring_order(rc);
         const int ring3[3] = {(rc + 7) % 8, rc, (rc + 1) % 8};
         const int ka = kRingK[ring3[ord & 3u]], kb = kRingK[ring3[(ord >> 2) & 3u]];
-        out->zero_t[rc][0] = static_cast<float>(thr[ka] * static_cast<double>(kThrScale));
-        out->zero_t[rc][1] = static_cast<float>(thr[kb] * static_cast<double>(kThrScale));
+        out->zero_e[rc] = thr_pack(thr[ka], thr[kb]);
     }
     double q[9], thr[9];
     for (int k = 0; k < 9; ++k) q[k] = k == 4 ? 0.0 : prior[k];
     thresholds(q, thr);
-    for (int k = 0; k < 9; ++k) out->thr9[k] = static_cast<float>(thr[k] * static_cast<double>(kThrScale));
+    for (int k = 0; k < 9; ++k) out->thr9[k] = thr_pack(thr[k], thr[k]) & 0xFFFFu;
 }
 
 extern "C" int ssrs_track_params_init(SsrsTrackParams *p, int rows, int cols,
@@ -2245,7 +2263,7 @@ extern "C" int ssrs_transition_ring_build(const double *updraft, const float *po
 extern "C" size_t ssrs_transition_thr_bytes(int rows, int cols)
 {
     if (rows <= 0 || cols <= 0) return 0;
-    return static_cast<size_t>(8) << thr_plane_shift(rows, cols);
+    return static_cast<size_t>(8) << thr_plane_shift(rows, cols);     // eight planes of rows * cols dwords
 }
 
 extern "C" int ssrs_transition_thr_build(const double *updraft, const float *potential,
@@ -2253,15 +2271,15 @@ extern "C" int ssrs_transition_thr_build(const double *updraft, const float *pot
 {
     SSRS_REQUIRE(updraft && thr && prior, "ssrs_transition_thr_build: updraft/prior/thr is NULL");
     SSRS_REQUIRE(rows >= 3 && cols >= 3, "ssrs_transition_thr_build: need rows, cols >= 3");
-    SSRS_REQUIRE(static_cast<size_t>(rows) * static_cast<size_t>(cols) <= (1ull << 26),
-                 "ssrs_transition_thr_build: the table is addressed with 32-bit offsets (rows * cols <= 2^26)");
+    SSRS_REQUIRE(static_cast<size_t>(rows) * static_cast<size_t>(cols) <= (1ull << 27),
+                 "ssrs_transition_thr_build: the table is addressed with 32-bit offsets (rows * cols <= 2^27)");
     SSRS_REQUIRE((reinterpret_cast<uintptr_t>(thr) & 63u) == 0,
                  "ssrs_transition_thr_build: table must be 64-byte aligned");
     ThrPrior pr;
     prior_tables(prior, &pr);
     const int tx = (cols + kTabW - 1) / kTabW, ty = (rows + kTabH - 1) / kTabH, nt = tx * ty;
     hipLaunchKernelGGL(k_transition_thr, dim3(static_cast<unsigned>(nt)), dim3(kBlock), 0, as_stream(stream),
-                       updraft, potential, thr, rows, cols, tx, nt, pr, thr_plane_shift(rows, cols));
+                       updraft, potential, reinterpret_cast<uint32_t *>(thr), rows, cols, tx, nt, pr, thr_plane_shift(rows, cols));
     SSRS_HIP_CHECK(hipGetLastError());
     return SSRS_OK;
 }
@@ -2388,8 +2406,8 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
         SSRS_REQUIRE(!ring && table && updraft && lean && a.fast && (S & 1) == 0,
                      "ssrs_tracks_simulate: SSRS_TRACKS_THR_TABLE needs table + updraft, memory_parameter 1, "
                      "scaling_parameter 1, no direct trajectory output, no EXACT_ONLY and an even steps_per_launch");
-        SSRS_REQUIRE(static_cast<size_t>(p->rows) * static_cast<size_t>(p->cols) <= (1ull << 26),
-                     "ssrs_tracks_simulate: the threshold table needs rows * cols <= 2^26");
+        SSRS_REQUIRE(static_cast<size_t>(p->rows) * static_cast<size_t>(p->cols) <= (1ull << 27),
+                     "ssrs_tracks_simulate: the threshold table needs rows * cols <= 2^27");
         prior_tables(p->prior, &thr_prior);
         a.plane_shift = thr_plane_shift(p->rows, p->cols);
     }

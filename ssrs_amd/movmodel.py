@@ -95,7 +95,7 @@ def make_track_params(grid_shape, move_dirn, memory_parameter=1, scaling_paramet
     return p
 
 
-THR_MAX_CELLS = 1 << 26        # the threshold table is addressed with 32-bit offsets
+THR_MAX_CELLS = 1 << 27        # the threshold table is addressed with 32-bit offsets
 
 
 def table_kind(table):
@@ -111,7 +111,7 @@ def build_transition_table(updraft, potential, ring=False, thr=False, move_dirn=
     """Per-cell move weights for the table stepper: 8 x f64 per cell (any
     memory_parameter); with ring=True the f32 ring table (10 x f32 per cell, a
     1-D float32 tensor) of the three-candidate stepper; with thr=True the threshold table
-    (16 x f32 per cell: the two decision thresholds for each of the eight last moves) of the
+    (8 dwords per cell: the two 16-bit decision thresholds for each of the eight last moves) of the
     threshold stepper -- it belongs to ONE heading, `move_dirn` (degrees).  Both f32 forms
     serve memory_parameter 1 / nu 1 only."""
     upd = to_dev(updraft, torch.float64)
