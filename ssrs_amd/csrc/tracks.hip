@@ -637,6 +637,8 @@ struct StepArgs {
     uint32_t cap;                // slots per XCD list (multiple of kBlock); list x = [x*cap, (x+1)*cap)
     long long it_base;           // k_step_thr: global iteration of this launch's first step
     int plane_shift;             // k_step_thr: log2 of the byte stride between the table's eight planes
+    int pf_dir, pf_rc;           // k_step_thr prefetch wave: row direction of the front (+1 north, -1 south),
+                                 // ring position of the heading
     uint32_t vcap;               // slots per XCD list in the visit buffer (= cap, or the launch's own
                                  // bound when its visits are recorded for trajectory output)
     const double *thr;           // [9][9] prior-fallback thresholds (k_prior_thresholds)
@@ -1392,13 +1394,113 @@ __global__ __launch_bounds__(kBlock) void k_transition_thr(
 // wave-uniform branches (each costs a lone wave ~25 clocks, taken or not):
 //   0 none, 1 visit buffer (plain keys), 2 visit buffer (transposed keys), 3 atomics on
 //   hist / its private copies
-template <int HM>
-__global__ __launch_bounds__(kBlock) void k_step_thr(const StepArgs a, const ThrPrior pr)
+// The fifth wave of a block (PF): the batch moves as a front, so every step touches table rows no
+// one has loaded yet and 4 of 5 gathers contain a lane that waits for HBM (87 % of the L2 requests
+// hit, but a 12-line gather waits for its slowest line).  A wave cannot prefetch for itself --
+// loads return to a wave in order, the needed gather would queue behind the prefetch -- but ANOTHER
+// wave can: this one steps no tracks; it reads where the block's 256 tracks are, and every eight
+// iterations it streams the table rows the front will reach 8..16 iterations later (three planes
+// around the heading, the block's column span plus a drift margin) through the XCD's L2 with
+// coalesced loads.  Paced by the iteration the stepping waves publish in LDS; nobody ever waits for
+// it, its waits are bounded, so it cannot hang the block.  North / south headings only (the span is
+// contiguous along a raster row).
+struct PfArgs {              // by value: taking the kernel arguments' address would move them to scratch
+    const int32_t *list_in;
+    const TrackState *state;
+    const void *table;
+    TrackCtl *ctl;
+    long long it_base;
+    uint32_t cap;
+    int coherent, steps, pf_dir, pf_rc, rows, cols, plane_shift;
+};
+__device__ __forceinline__ void thr_prefetch_wave(const PfArgs a, uint32_t xcd, uint32_t nlive, const volatile int *s_it)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t base = (blockIdx.x / kXcd) * kBlock;
+    int vr_lo = 0x7fffffff, vr_hi = -0x7fffffff, c_lo = 0x7fffffff, c_hi = -0x7fffffff;
+    for (int q = 0; q < kBlock / 64; ++q) {
+        const uint32_t il = base + q * 64 + lane;
+        if (il >= nlive) continue;
+        const uint32_t i = xcd * a.cap + il;
+        const int32_t t = a.list_in ? a.list_in[i] : static_cast<int32_t>(i);
+        const TrackState s = a.state[t];
+        if (s.k < 0) continue;
+        const int row = s.pos & 0xFFFF, col = (s.pos >> 16) & 0xFFFF;
+        const long long rel64 = (a.coherent ? static_cast<long long>(s.aux >> 9) : 0) + 1 - a.it_base;
+        const int rel = rel64 > a.steps ? a.steps : (rel64 < 0 ? 0 : static_cast<int>(rel64));
+        const int vr = row - a.pf_dir * rel;              // row at iteration `it` (once released): vr + pf_dir * it
+        vr_lo = vr < vr_lo ? vr : vr_lo;  vr_hi = vr > vr_hi ? vr : vr_hi;
+        c_lo = col < c_lo ? col : c_lo;   c_hi = col > c_hi ? col : c_hi;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        int o = __shfl_xor(vr_lo, off); vr_lo = o < vr_lo ? o : vr_lo;
+        o = __shfl_xor(vr_hi, off); vr_hi = o > vr_hi ? o : vr_hi;
+        o = __shfl_xor(c_lo, off); c_lo = o < c_lo ? o : c_lo;
+        o = __shfl_xor(c_hi, off); c_hi = o > c_hi ? o : c_hi;
+    }
+    if (vr_lo > vr_hi) return;                            // no live track in this block
+    if (vr_hi - vr_lo > 16) vr_hi = vr_lo + 16;           // stragglers are not worth rows of traffic
+    const char *tab = reinterpret_cast<const char *>(a.table);
+    uint32_t acc = 0;
+    constexpr int kEvery = 8, kLead = 8;
+    for (int it0 = 0; it0 < a.steps; it0 += kEvery) {
+        // stay at most kEvery iterations ahead of the block's stepping waves; leave with them
+        for (int spin = 0; spin < 4096 && *s_it < it0 - kEvery; ++spin) __builtin_amdgcn_s_sleep(16);
+        if (*s_it >= 0x3fffffff) break;
+        const int margin = 8 + static_cast<int>(2.5f * sqrtf(static_cast<float>(it0 + kLead + kEvery)));
+        int c0 = c_lo - margin, c1 = c_hi + margin;
+        c0 = c0 < 0 ? 0 : c0;
+        c1 = c1 >= a.cols ? a.cols - 1 : c1;
+        // rows the front reaches at iterations [it0 + kLead, it0 + kLead + kEvery)
+        const int first = (a.pf_dir > 0 ? vr_lo : vr_hi) + a.pf_dir * (it0 + kLead);
+        const int nrow = kEvery + (vr_hi - vr_lo);
+        const uint32_t span = static_cast<uint32_t>(c1 - c0) + 1u;
+        // four rows at a time, two 512-byte pieces of three planes each: 24 loads in flight
+        for (int j0 = 0; j0 < nrow; j0 += 4) {
+            uint32_t v[24];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int r = first + a.pf_dir * (j0 + jj);
+                const bool row_ok = j0 + jj < nrow && r >= 0 && r < a.rows;
+                const uint32_t cellb = static_cast<uint32_t>(row_ok ? r : 0) * static_cast<uint32_t>(a.cols) + static_cast<uint32_t>(c0);
+                const uint32_t lo = (cellb & ~1u) * 4u;                  // 8-byte aligned
+                const uint32_t hi = (cellb + span) * 4u;                 // end (exclusive)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    const uint32_t plane = static_cast<uint32_t>((a.pf_rc + 7 + p) & 7) << a.plane_shift;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t off = lo + static_cast<uint32_t>(lane) * 8u + static_cast<uint32_t>(h) * 512u;
+                        v[(jj * 3 + p) * 2 + h] = (row_ok && off < hi) ? reinterpret_cast<const uint2 *>(tab + (plane | off))->x : 0u;
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 24; ++q) acc ^= v[q];
+        }
+    }
+    if (acc == 0x9E3779B9u && a.steps < 0) a.ctl->pad = 1;      // keeps the loads alive
+}
+
+template <int HM, bool PF = false>
+__global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const StepArgs a, const ThrPrior pr)
 {
     TrackCtl *ctl = a.ctl;
     const int in_slot = a.launch & 3, out_slot = (a.launch + 1) & 3;
     const uint32_t xcd = blockIdx.x % kXcd;
     const uint32_t nlive = ctl->count[in_slot][xcd];
+    __shared__ int s_it;                                  // PF: iteration reached by the stepping waves
+    if (PF) {
+        if (threadIdx.x == 0) s_it = -1;
+        __syncthreads();
+        if (threadIdx.x >= kBlock) {
+            const PfArgs pa = {a.list_in, a.state, a.table, a.ctl, a.it_base, a.cap, a.coherent, a.steps,
+                               a.pf_dir, a.pf_rc, a.rows, a.cols, a.plane_shift};
+            thr_prefetch_wave(pa, xcd, nlive, &s_it);
+            return;
+        }
+    }
     const uint32_t il = (blockIdx.x / kXcd) * kBlock + threadIdx.x;
     const uint32_t i = xcd * a.cap + il;
     const uint32_t iv = xcd * a.vcap + il;
@@ -1453,6 +1555,7 @@ __global__ __launch_bounds__(kBlock) void k_step_thr(const StepArgs a, const Thr
     int it = 0;
 
     auto one_step = [&](const bool even, const bool burn) {
+        if (PF && even && (it & 7) == 0 && (threadIdx.x & 63) == 0) atomicMax(&s_it, it);
         // st: all ones when this lane steps now
         const uint32_t stm = (static_cast<uint32_t>(it - rel) < span) ? 0xFFFFFFFFu : 0u;
         uint32_t w0, w1;
@@ -1564,6 +1667,7 @@ __global__ __launch_bounds__(kBlock) void k_step_thr(const StepArgs a, const Thr
             *vrow = 0xFFFFFFFFu;
             vrow += a.visit_stride;
         }
+    if (PF && (threadIdx.x & 63) == 0) atomicMax(&s_it, 0x3fffffff);   // nothing left to wait for
 
     // a track whose span is used up is finished: it ended at the raster's edge or took max_moves
     const bool active = live0 && span != 0u && k < static_cast<int>(a.max_k);
@@ -2410,6 +2514,10 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                      "ssrs_tracks_simulate: the threshold table needs rows * cols <= 2^27");
         prior_tables(p->prior, &thr_prior);
         a.plane_shift = thr_plane_shift(p->rows, p->cols);
+        // prefetch wave: the heading's ring position (0 = north, 4 = south); A/B switch SSRS_TRACKS_NO_PREFETCH
+        a.pf_dir = (coherent && std::getenv("SSRS_TRACKS_NO_PREFETCH") == nullptr)
+                       ? (geom.cos_t > 0.98 ? 1 : (geom.cos_t < -0.98 ? -1 : 0)) : 0;
+        a.pf_rc = a.pf_dir < 0 ? 4 : 0;
     }
     const int mode0 = updraft ? (potential ? MODE_FLUIDFLOW : MODE_UPDRAFT) : MODE_PRIOR;   // thr: first move
     if (ring)
@@ -2557,9 +2665,14 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
             switch (first_move ? mode0 : mode) {
             case MODE_TABLE:
                 if (thr) {
+                    // front-shaped batches heading north / south get the prefetch wave
+                    const bool pf = a.pf_dir != 0 && a.coherent && !scattered;
                     if (a.visits && hist_t && binning_on) hipLaunchKernelGGL((k_step_thr<2>), dim3(blocks), dim3(kBlock), 0, st, a, thr_prior);
+                    else if (a.visits && pf) hipLaunchKernelGGL((k_step_thr<1, true>), dim3(blocks), dim3(kBlock + 64), 0, st, a, thr_prior);
                     else if (a.visits) hipLaunchKernelGGL((k_step_thr<1>), dim3(blocks), dim3(kBlock), 0, st, a, thr_prior);
+                    else if (a.hist && pf) hipLaunchKernelGGL((k_step_thr<3, true>), dim3(blocks), dim3(kBlock + 64), 0, st, a, thr_prior);
                     else if (a.hist) hipLaunchKernelGGL((k_step_thr<3>), dim3(blocks), dim3(kBlock), 0, st, a, thr_prior);
+                    else if (pf) hipLaunchKernelGGL((k_step_thr<0, true>), dim3(blocks), dim3(kBlock + 64), 0, st, a, thr_prior);
                     else hipLaunchKernelGGL((k_step_thr<0>), dim3(blocks), dim3(kBlock), 0, st, a, thr_prior);
                     break;
                 }
