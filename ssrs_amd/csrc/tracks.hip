@@ -2162,6 +2162,31 @@ __global__ __launch_bounds__(kBlock) void k_gather_chunk(const TrajChunk ch, uin
     cursor[t] = c;
 }
 
+// Re-deals the live tracks over the kXcd lists (a pseudo-launch between two stepper launches).
+// The lists are column bands, dealt to the XCDs; when the survivors of a batch sit in one or two
+// bands -- tracks that wander in a few basins of the potential field until max_moves -- one XCD
+// steps them all while seven idle, and the launch grid, sized by the longest list, stays large.
+__global__ __launch_bounds__(1024) void k_rebalance_lists(const int32_t *__restrict__ list_in, int32_t *__restrict__ list_out,
+                                                         TrackCtl *ctl, int in_slot, int out_slot, int zero_slot, uint32_t cap)
+{
+    __shared__ uint32_t pre[kXcd + 1];
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int x = 0; x < kXcd; ++x) { pre[x] = run; run += ctl->count[in_slot][x]; ctl->count[zero_slot][x] = 0; }
+        pre[kXcd] = run;
+    }
+    __syncthreads();
+    const uint32_t total = pre[kXcd];
+    for (uint32_t j = threadIdx.x; j < total; j += 1024) {
+        int x = 0;
+#pragma unroll
+        for (int y = 1; y < kXcd; ++y) x += pre[y] <= j ? 1 : 0;
+        list_out[(j & (kXcd - 1)) * cap + (j >> 3)] = list_in[static_cast<uint32_t>(x) * cap + (j - pre[x])];
+    }
+    if (threadIdx.x < kXcd) ctl->count[out_slot][threadIdx.x] = (total + kXcd - 1 - threadIdx.x) / kXcd;
+}
+static_assert(kXcd == 8, "k_rebalance_lists deals with j & 7 / j >> 3");
+
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Workspace {
@@ -2583,6 +2608,11 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
     for (int i = 0; i < kRing; ++i) SSRS_HIP_CHECK(hipEventCreate(&ev_batch[i]));
     std::vector<hipEvent_t> ev_prof, ev_bin, ev_hist;   // launch starts / ends; binning kernel brackets
     int launch = 0;
+    long long it_done = 0;                   // threshold stepper: iterations of the launches so far (after the first move)
+    bool want_rebalance = false;
+    int rebalance_cooldown = 0;              // batches to look past after a re-deal (their counts are older than it)
+    const bool may_rebalance = std::getenv("SSRS_TRACKS_NO_REBALANCE") == nullptr;
+    const bool grow_steps = std::getenv("SSRS_TRACKS_FIXED_STEPS") == nullptr;      // A/B switch
     // bound on the longest XCD list
     uint32_t upper = static_cast<uint32_t>(ntracks < static_cast<int64_t>(ws.cap) ? ntracks : ws.cap);
     int batches = 0, checked = 0, judge_from = 0;
@@ -2592,6 +2622,14 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
     // Termination: every live track either finishes or takes S moves per
     // launch and k < max_moves, so the live count reaches 0.
     while (!finished && rc == SSRS_OK) {
+        if (want_rebalance && launch > 0) {
+            // pseudo-launch: list[launch & 1] -> list[(launch + 1) & 1], counts likewise
+            hipLaunchKernelGGL(k_rebalance_lists, dim3(1), dim3(1024), 0, st, ws.list[launch & 1], ws.list[(launch + 1) & 1],
+                               ws.ctl, launch & 3, (launch + 1) & 3, (launch + 2) & 3, ws.cap);
+            ++launch;
+            want_rebalance = false;
+            rebalance_cooldown = 3;
+        }
         for (int j = 0; j < kBatch; ++j, ++launch) {
             a.launch = launch;
             a.list_in = (launch == 0 && !coherent) ? nullptr : ws.list[launch & 1];
@@ -2599,11 +2637,30 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
             // threshold table: launch 0 is ONE iteration of the window-gather kernel for every
             // track at once (the first move has eight admissible cells), the rest are S deep
             const bool first_move = thr && launch == 0;
-            const int Sl = first_move ? 1 : S;
+            const unsigned blocks = kXcd * ((upper + kBlock - 1) / kBlock);
+            int Sl = first_move ? 1 : S;
+            uint32_t vcap_l = ws.cap;
+            long long vstride_l = ws.visit_stride;
+            if (thr && !first_move && (binning_on || tiles_on) && !(rec && rec->complete) && grow_steps) {
+                // Few live tracks left (the long tail of a batch; tracks that wander until max_moves):
+                // the visit buffer then holds MORE iterations of the shrunken lists, and a launch of
+                // up to 8 S steps amortises the per-launch kernels (binning, read-back) over them
+                const uint32_t vc = (blocks / kXcd) * kBlock;                   // slots per list this launch
+                const long long room = (ws.visit_stride * kVisitSteps) / (static_cast<long long>(kXcd) * vc);
+                long long grown = room < 8ll * S ? room : 8ll * S;
+                grown &= ~1ll;
+                if (grown >= S + S / 4) {
+                    Sl = static_cast<int>(grown);
+                    vcap_l = vc;
+                    vstride_l = static_cast<long long>(kXcd) * vc;
+                }
+            }
+            if (std::getenv("SSRS_TRACKS_DEBUG") && (launch < 40 || launch % 500 == 0))
+                fprintf(stderr, "[tracks] launch %d upper %u blocks %u Sl %d binning %d tiles %d scattered %d cap %u\n", launch, upper, blocks, Sl,
+                        binning_on ? 1 : 0, tiles_on ? 1 : 0, scattered ? 1 : 0, ws.cap);
             a.steps = Sl;
             a.coherent = (coherent && !first_move) ? 1 : 0;
-            a.it_base = thr && launch > 0 ? static_cast<long long>(launch - 1) * S : 0;
-            const unsigned blocks = kXcd * ((upper + kBlock - 1) / kBlock);
+            a.it_base = thr && launch > 0 ? it_done : 0;
             a.visits = nullptr;
             if (!binning_on && scattered && copies_ptr && !copies_live) {
                 // first scattered launch: zero the private copies, count into them from now on
@@ -2621,8 +2678,8 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
             const uint32_t keep_r = a.vis_r, keep_c = a.vis_c;
             if (first_move) { a.vis_r = static_cast<uint32_t>(p->cols); a.vis_c = 1u; }
             if (bin_window || bin_tiles) a.visits = ws.visits;
-            a.visit_stride = ws.visit_stride;
-            a.vcap = ws.cap;
+            a.visit_stride = vstride_l;
+            a.vcap = vcap_l;
             const uint32_t *rec_counts = nullptr;
             if (rec && rec->complete) {
                 // this launch's own region of the pool: [counts][slot -> track list][visits]
@@ -2741,6 +2798,7 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                                    static_cast<uint32_t>(ncell));
             a.vis_r = keep_r;
             a.vis_c = keep_c;
+            if (thr && !first_move) it_done += Sl;
             if (hipGetLastError() != hipSuccess) { rc = set_error(SSRS_ERR_HIP, "stepper launch failed"); break; }
         }
         if (rc != SSRS_OK) break;
@@ -2767,6 +2825,12 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
             ++checked;
             if (c == 0) { finished = true; break; }
             upper = c;   // the live count only shrinks; a stale bound is safe
+            if (thr && may_rebalance) {
+                uint32_t total = 0;
+                for (int x = 0; x < kXcd; ++x) total += host_counts[16 * cs + x];
+                if (rebalance_cooldown > 0) --rebalance_cooldown;
+                else if (c >= 1024 && 5ull * c >= static_cast<unsigned long long>(total) + 64ull) want_rebalance = true;   // longest list >= 1.6 x the mean
+            }
             // binning pays only while the batch moves as a front: once more than a
             // quarter of a batch's visits miss the LDS window, later launches go back
             // to in-stepper atomics
@@ -2794,7 +2858,7 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
             // batches that never binned (small, unsorted, very wide rasters) give no stray
             // signal: tracks still alive after four raster crossings are wandering
             if (!binning_on && !tiles_on && !scattered && !never_scattered &&
-                static_cast<long long>(launch) * S > 4ll * (p->rows + p->cols))
+                (thr ? it_done : static_cast<long long>(launch) * S) > 4ll * (p->rows + p->cols))
                 scattered = true;
             seen_steps = tot[0];
             seen_strays = tot[1];
