@@ -49,12 +49,17 @@ class HistogramOverflow(OverflowError):
 def _max_bound(hist, group):
     """Sum over ranks of each rank's largest count (int64 scalar tensor): an upper bound
     of the largest count of the reduced histogram."""
-    flat = hist.view(torch.int32).reshape(-1)
-    # uint32 stored in int32: the largest unsigned value is the min of the negatives if any
-    neg = flat.min()
-    local = torch.where(neg < 0, neg.to(torch.int64) + (1 << 32), flat.max().to(torch.int64)).reshape(1)
+    local = _local_max(hist.view(torch.int32).reshape(-1))
     dist.all_reduce(local, op=dist.ReduceOp.SUM, group=group)
     return local
+
+
+def _local_max(flat):
+    """Upper bound of the largest count of a uint32-in-int32 histogram as an int64 scalar
+    tensor: one pass (aminmax), no host synchronisation.  A negative int32 is a count >= 2^31;
+    any such count makes the bound 2^32 - 1 (conservative: the guard then takes the wide path)."""
+    lo, hi = torch.aminmax(flat)
+    return torch.where(lo < 0, torch.full_like(hi, 0, dtype=torch.int64) + ((1 << 32) - 1), hi.to(torch.int64)).reshape(1)
 
 
 class _GuardedWork:
@@ -105,9 +110,7 @@ def reduce_histogram(hist, dst=0, group=None, all_ranks=False, async_op=False, g
     if async_op:
         bound = bound_work = None
         if guard:
-            neg = flat.min()
-            bound = torch.where(neg < 0, neg.to(torch.int64) + (1 << 32),
-                                flat.max().to(torch.int64)).reshape(1)
+            bound = _local_max(flat)
             bound_work = dist.all_reduce(bound, op=dist.ReduceOp.SUM, group=group, async_op=True)
         return _GuardedWork(run(flat, async_op=True), bound_work, bound)
     if guard and int(_max_bound(hist, group).item()) >= (1 << 32):
