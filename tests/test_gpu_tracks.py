@@ -782,3 +782,43 @@ def test_thr_table_belongs_to_one_heading(gpu):
         movmodel.simulate_tracks(90., [[5, 5]], (40, 50), 1, 1., upd, pot, table=table)
     with pytest.raises(ValueError):
         movmodel.build_transition_table(upd, pot, thr=True)
+
+
+def test_one_band_batch_is_redealt_over_the_lists(gpu):
+    """All tracks start in one eighth of the raster's width: seven of the eight per-XCD lists are
+    empty, the host re-deals the live tracks (k_rebalance_lists pseudo-launch) and grows the
+    launches to the visit buffer's room; lengths, end cells, histogram and recorded trajectories
+    must not notice (SSRS_TRACKS_NO_REBALANCE / _FIXED_STEPS are the A/B switches)."""
+    import os
+    from ssrs_amd import movmodel
+    from oracle import c_oracle
+    rows, cols = 420, 900
+    upd, pot = _random_field_case(rows, cols, 12)
+    pot = pot.copy()
+    rr, cc = np.arange(rows)[:, None], np.arange(cols)[None, :]
+    for r0, c0 in ((150, 60), (260, 95), (330, 40)):          # wells: detours, a few tracks circle until max_moves
+        pot -= (600. * np.exp(-((rr - r0) ** 2 + (cc - c0) ** 2) / (2. * 9. ** 2))).astype(np.float32)
+    rng = np.random.default_rng(21)
+    n = 12000
+    starts = np.stack([rng.integers(2, 30, n), rng.integers(5, 110, n)], 1)
+    cap = 6000
+    ref = c_oracle.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=8, max_moves=cap)
+    got = movmodel.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=8, use_table=True, thr=True,
+                                   max_moves=cap, steps_per_launch=64)
+    assert np.array_equal(got.lengths.cpu().numpy(), ref['lengths'])
+    assert np.array_equal(got.ends.cpu().numpy(), ref['ends'])
+    assert np.array_equal(got.hist.cpu().numpy().view(np.uint32), ref['hist'])
+    rec = movmodel.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=8, use_table=True, thr=True,
+                                   max_moves=cap, steps_per_launch=64, want_tracks=True)
+    assert rec.stats['recorded']
+    assert np.array_equal(rec.traj.cpu().numpy(), np.concatenate(ref['tracks']))
+    assert torch.equal(rec.hist, got.hist)
+    os.environ['SSRS_TRACKS_NO_REBALANCE'] = '1'
+    os.environ['SSRS_TRACKS_FIXED_STEPS'] = '1'
+    try:
+        plain = movmodel.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=8, use_table=True, thr=True,
+                                         max_moves=cap, steps_per_launch=64)
+    finally:
+        del os.environ['SSRS_TRACKS_NO_REBALANCE'], os.environ['SSRS_TRACKS_FIXED_STEPS']
+    assert torch.equal(plain.hist, got.hist) and torch.equal(plain.lengths, got.lengths)
+    assert plain.stats['launches'] > got.stats['launches'], 'the re-deal / grown launches did not happen'
