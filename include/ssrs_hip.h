@@ -231,9 +231,9 @@ size_t ssrs_transition_thr_bytes(int rows, int cols);
 int ssrs_transition_thr_build(const double *updraft, const float *potential, const double *prior,
                               float *thr, int rows, int cols, void *stream);
 
-/* Bytes of device scratch ssrs_tracks_simulate needs for `ntracks` (about 4.2 KB per
- * track: two buffers of 512 steps x 4 B for the launch's visited cells, in slot and in
- * raster-tile order). */
+/* Bytes of device scratch ssrs_tracks_simulate needs for `ntracks` (about 8.3 KB per
+ * track: two buffers of 1024 steps x 4 B for the launch's visited cells, in slot and in
+ * raster-tile order; a launch takes as many steps as they hold for the live tracks). */
 size_t ssrs_tracks_workspace_bytes(int64_t ntracks);
 /* The same plus room for `hist_copies` (2..64) private copies of the histogram.  A
  * workspace of this size lets ssrs_tracks_simulate privatise the histogram once a batch

@@ -637,6 +637,7 @@ struct StepArgs {
     uint32_t cap;                // slots per XCD list (multiple of kBlock); list x = [x*cap, (x+1)*cap)
     long long it_base;           // k_step_thr: global iteration of this launch's first step
     int plane_shift;             // k_step_thr: log2 of the byte stride between the table's eight planes
+    int v16_offset;              // k_step_thr<4>: plan offset (rows + cols): first start row = ctl->par_min - v16_offset
     int pf_dir, pf_rc;           // k_step_thr prefetch wave: row direction of the front (+1 north, -1 south),
                                  // ring position of the heading
     uint32_t vcap;               // slots per XCD list in the visit buffer (= cap, or the launch's own
@@ -1253,11 +1254,12 @@ __device__ __forceinline__ void split_cell(uint32_t c, uint32_t cols, double inv
 //     T1 = round(2^16 a / (a + b + c)),   T2 = round(2^16 (a + b) / (a + b + c))   (a b c in ascending k,
 //     both clamped to 65535)
 // and a step is: one 4-byte gather, two integer subtractions from the top 16 bits of the uniform,
-// two sign bits -> the chosen cell.  |T - 2^16 cdf_k/cdf_8| <= 0.5 (rounding; the f64 quotient
-// differs from the reference's normalise-twice sequence by 1e-15; the clamp only matters where
+// two sign bits -> the chosen cell.  |T - 2^16 cdf_k/cdf_8| <= 0.52 (rounding 0.5; the builder's
+// reciprocal estimates and f32 packing 2e-7 relative; the reference's normalise-twice sequence
+// 1e-15; the clamp only matters where
 // the uniform's top bits are 65534 / 65535, which the band covers) and the uniform's top 16 bits
 // ufi satisfy ufi <= 2^16 u < ufi + 1, so ufi - T >= 1 means cdf_k/cdf_8 <= u and ufi - T <= -2
-// means it is not: the decision is the reference's unless ufi - T is -1 or 0 (3e-5 per boundary),
+// means it is not (0.48 units of margin either way): the decision is the reference's unless ufi - T is -1 or 0 (3e-5 per boundary),
 // where the exact sequence on the raw windows decides.  Everything irregular is an entry with
 // T1 > T2 (impossible otherwise): T1 = 0xFFFF and T2 =
 //   0  poisoned row    (a NaN / infinite weight: exact sequence, movmodel.py:228-230)
@@ -1273,7 +1275,6 @@ __device__ __forceinline__ void split_cell(uint32_t c, uint32_t cols, double inv
 // Eight planes (one per last move) of 4-byte entries: neighbouring tracks gather from the same
 // few cache lines (32 cells per 128-byte line), which is what the CU's address unit charges for.
 constexpr uint32_t kThrPoison = 0x0000FFFFu, kThrBoundary = 0x0001FFFFu, kThrReversal = 0x0002FFFFu;
-constexpr double kThrScale = 65536.0;
 
 // The table is eight planes (one per last move rc) of 4-byte entries, plane p at byte offset
 // p << thr_plane_shift: a power-of-two stride makes a step's address one shift-or
@@ -1285,19 +1286,18 @@ __host__ __device__ constexpr int thr_plane_shift(int rows, int cols)
     return sh;
 }
 
-// 1 / x to ~1e-16: hardware estimate + one Newton step (inf / NaN / 0 propagate as such)
+// 1 / x as the hardware estimates it: v_rcp_f64 is good to 4.6e-8 on gfx950 (tools/microbench/rcp.hip),
+// 0.003 units of a 16-bit threshold (inf / NaN / 0 propagate as such)
 __device__ __forceinline__ double fast_rcp(double x)
 {
-    const double r = __builtin_amdgcn_rcp(x);
-    const double c = r * (2.0 - x * r);
-    return (c - c == 0.0) ? c : r;            // keep the estimate's inf / NaN / 0 (x = 0, inf, NaN)
+    return __builtin_amdgcn_rcp(x);
 }
 
 __host__ __device__ __forceinline__ uint32_t thr_pack(double b1, double b2)
-{   // two boundaries in [0, 1] -> T1 | T2 << 16
-    double t1 = b1 * kThrScale + 0.5, t2 = b2 * kThrScale + 0.5;      // round half up (values >= 0)
-    uint32_t u1 = t1 >= 65535.0 ? 65535u : static_cast<uint32_t>(t1);
-    uint32_t u2 = t2 >= 65535.0 ? 65535u : static_cast<uint32_t>(t2);
+{   // two boundaries in [0, 1] -> T1 | T2 << 16 (f32 is plenty: 24 bits against 16)
+    const float t1 = static_cast<float>(b1) * 65536.0f + 0.5f, t2 = static_cast<float>(b2) * 65536.0f + 0.5f;   // round half up
+    uint32_t u1 = t1 >= 65535.0f ? 65535u : static_cast<uint32_t>(t1);
+    uint32_t u2 = t2 >= 65535.0f ? 65535u : static_cast<uint32_t>(t2);
     if (u1 > u2) u1 = u2;                                              // b1 <= b2 up to rounding
     return u1 | (u2 << 16);
 }
@@ -1393,7 +1393,10 @@ __global__ __launch_bounds__(kBlock) void k_transition_thr(
 // Histogram mode of k_step_thr, a template parameter so that the loop body carries no
 // wave-uniform branches (each costs a lone wave ~25 clocks, taken or not):
 //   0 none, 1 visit buffer (plain keys), 2 visit buffer (transposed keys), 3 atomics on
-//   hist / its private copies
+//   hist / its private copies, 4 visit buffer with 16-bit keys relative to the front's row
+//   (north-bound fronts: a visit is its offset from cell (first start row + iteration - 1, 0);
+//   halves what the stepper writes and k_bin_visits16 reads; a visit out of that range is
+//   counted by the lane itself)
 // The fifth wave of a block (PF): the batch moves as a front, so every step touches table rows no
 // one has loaded yet and 4 of 5 gathers contain a lane that waits for HBM (87 % of the L2 requests
 // hit, but a 12-line gather waits for its slowest line).  A wave cannot prefetch for itself --
@@ -1549,6 +1552,10 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
     uint32_t colv = static_cast<uint32_t>(s.pos >> 16) & 0xFFFFu;
     const uint32_t zone_lo = 2u * ucols, zone_hi = (urows - 2u) * ucols, zone_col = ucols - 2u;
     uint32_t *vrow = (HM == 1 || HM == 2) ? a.visits + iv : nullptr;              // this lane's slot, row `it`
+    uint16_t *vrow16 = HM == 4 ? reinterpret_cast<uint16_t *>(a.visits) + iv : nullptr;
+    // HM 4: cell (first start row + global iteration - 1, 0); may start below 0: compared as int
+    int32_t vbase = HM == 4 ? (static_cast<int32_t>(ctl->par_min) - a.v16_offset + static_cast<int32_t>(a.it_base) - 1) *
+                                  static_cast<int32_t>(ucols) : 0;
     uint32_t *hbase = a.hist;
     if (HM == 3 && a.hist_copies)
         hbase = a.hist_copies + static_cast<size_t>((i >> 6) % static_cast<uint32_t>(a.ncopies)) * static_cast<size_t>(ncell);
@@ -1648,6 +1655,17 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
             vrow += a.visit_stride;
         } else if (HM == 3) {
             atomicAdd(&hbase[cell], go & 1u);
+        } else if (HM == 4) {
+            const uint32_t key = static_cast<uint32_t>(static_cast<int32_t>(cell) - vbase);
+            const bool stray = (go != 0u) & (key >= 0xFFFFu);
+            if (__builtin_expect(__any(stray), 0)) {
+                if (stray) atomicAdd(&a.hist[cell], 1u);
+                const unsigned long long sm = __ballot(stray);
+                if ((threadIdx.x & 63) == 0) atomicAdd(&ctl->strays, static_cast<unsigned long long>(__popcll(sm)));
+            }
+            *vrow16 = static_cast<uint16_t>((go != 0u && !stray) ? key : 0xFFFFu);
+            vrow16 += a.visit_stride;
+            vbase += static_cast<int32_t>(ucols);
         }
         ++it;
     };
@@ -1666,6 +1684,11 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
         for (; it < a.steps; ++it) {
             *vrow = 0xFFFFFFFFu;
             vrow += a.visit_stride;
+        }
+    if (HM == 4)
+        for (; it < a.steps; ++it) {
+            *vrow16 = 0xFFFFu;
+            vrow16 += a.visit_stride;
         }
     if (PF && (threadIdx.x & 63) == 0) atomicMax(&s_it, 0x3fffffff);   // nothing left to wait for
 
@@ -1807,6 +1830,72 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_visits(const uint32_t *__re
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             if (n[q]) atomicAdd(&hist[base + k + q * kBinThreads], n[q]);
+    }
+}
+
+
+// K3 for 16-bit visit keys (k_step_thr<4>): block b bins iterations 2b and 2b + 1 of the launch into
+// ONE LDS window; a key is the visit's offset from cell (first start row + global iteration - 1, 0),
+// so the window is simply the first kBinCells offsets from the first iteration's base (the front's
+// rows sit at offsets [2 cols, 4 cols), one row further for the second iteration).  Two iterations
+// per block halve the zeroing / flushing of the 120-KB window, the larger part of this kernel.
+__global__ __launch_bounds__(kBinThreads) void k_bin_visits16(const uint16_t *__restrict__ visits, long long stride, int steps,
+                                                             TrackCtl *__restrict__ ctl, int slot,
+                                                             uint32_t *__restrict__ hist, int rows, int cols, uint32_t cap,
+                                                             int v16_offset, long long it_base)
+{
+    __shared__ uint32_t bins[kBinCells];
+    uint32_t nslots[kXcd];
+#pragma unroll
+    for (int x = 0; x < kXcd; ++x) nslots[x] = (ctl->count[slot][x] + 63u) & ~63u;
+    const int it0 = 2 * static_cast<int>(blockIdx.x);
+    const long long base = (static_cast<long long>(ctl->par_min) - v16_offset + it_base + it0 - 1) * cols;
+    for (int k = threadIdx.x; k < kBinCells; k += kBinThreads) bins[k] = 0;
+    __syncthreads();
+    uint32_t stray = 0;
+    constexpr int kU = 8;                                  // 8 x 2 keys in flight per thread
+    for (int sub = 0; sub < 2 && it0 + sub < steps; ++sub) {
+        const uint16_t *v = visits + static_cast<long long>(it0 + sub) * stride;
+        const uint32_t shift = sub ? static_cast<uint32_t>(cols) : 0u;       // the second iteration's base is one row up
+#pragma unroll
+        for (int x = 0; x < kXcd; ++x) {
+            const uint32_t *v2 = reinterpret_cast<const uint32_t *>(v + static_cast<size_t>(x) * cap);   // cap is a multiple of 256
+            const uint32_t npair = nslots[x] / 2;
+            for (uint32_t j = threadIdx.x; j < npair; j += kBinThreads * kU) {
+                uint32_t c[kU];
+#pragma unroll
+                for (int q = 0; q < kU; ++q) {
+                    const uint32_t jj = j + q * kBinThreads;
+                    c[q] = jj < npair ? v2[jj] : 0xFFFFFFFFu;
+                }
+#pragma unroll
+                for (int q = 0; q < kU; ++q) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        uint32_t key = h ? c[q] >> 16 : c[q] & 0xFFFFu;
+                        if (key == 0xFFFFu) continue;      // idle slot (or counted by the stepper)
+                        key += shift;
+                        if (key < kBinCells) atomicAdd(&bins[key], 1u);
+                        else { atomicAdd(&hist[base + key], 1u); ++stray; }     // in the raster: a visited cell
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) stray += __shfl_down(stray, off);
+    if ((threadIdx.x & 63) == 0 && stray) atomicAdd(&ctl->strays, static_cast<unsigned long long>(stray));
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < kBinCells; k += kBinThreads * 4) {
+        uint32_t n[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t kk = k + q * kBinThreads;
+            n[q] = kk < kBinCells ? bins[kk] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (n[q]) atomicAdd(&hist[base + k + q * kBinThreads], n[q]);     // n > 0: a visited cell, inside the raster
     }
 }
 
@@ -2204,7 +2293,7 @@ struct Workspace {
     uint32_t cap;                // slots per XCD list
 };
 
-constexpr int kVisitSteps = 512;   // binning mode covers launches of up to this many steps
+constexpr int kVisitSteps = 1024;  // binning mode covers launches of up to this many steps
 
 static size_t sort_temp_size(int64_t n)
 {
@@ -2613,6 +2702,8 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
     int rebalance_cooldown = 0;              // batches to look past after a re-deal (their counts are older than it)
     const bool may_rebalance = std::getenv("SSRS_TRACKS_NO_REBALANCE") == nullptr;
     const bool grow_steps = std::getenv("SSRS_TRACKS_FIXED_STEPS") == nullptr;      // A/B switch
+    const bool v16_ok = 5ll * p->cols <= kBinCells && std::getenv("SSRS_TRACKS_NO_VISITS16") == nullptr;
+    a.v16_offset = geom.offset;
     // bound on the longest XCD list
     uint32_t upper = static_cast<uint32_t>(ntracks < static_cast<int64_t>(ws.cap) ? ntracks : ws.cap);
     int batches = 0, checked = 0, judge_from = 0;
@@ -2719,11 +2810,17 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                 hipEvent_t e;
                 if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); ev_prof.push_back(e); }
             }
+            // 16-bit visit keys: north-bound front through the row window, nothing recorded
+            const bool v16 = thr && bin_window && a.visits == ws.visits && a.pf_dir == 1 && !hist_t && v16_ok;
             switch (first_move ? mode0 : mode) {
             case MODE_TABLE:
                 if (thr) {
                     // front-shaped batches heading north / south get the prefetch wave
                     const bool pf = a.pf_dir != 0 && a.coherent && !scattered;
+                    if (v16) {
+                        hipLaunchKernelGGL((k_step_thr<4, true>), dim3(blocks), dim3(kBlock + 64), 0, st, a, thr_prior);
+                        break;
+                    }
                     if (a.visits && hist_t && binning_on) hipLaunchKernelGGL((k_step_thr<2>), dim3(blocks), dim3(kBlock), 0, st, a, thr_prior);
                     else if (a.visits && pf) hipLaunchKernelGGL((k_step_thr<1, true>), dim3(blocks), dim3(kBlock + 64), 0, st, a, thr_prior);
                     else if (a.visits) hipLaunchKernelGGL((k_step_thr<1>), dim3(blocks), dim3(kBlock), 0, st, a, thr_prior);
@@ -2754,7 +2851,10 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                 ++window_launches;
                 hipEvent_t b0 = nullptr, b1 = nullptr;
                 if (profile && hipEventCreate(&b0) == hipSuccess) (void)hipEventRecord(b0, st);
-                if (hist_t)
+                if (v16)
+                    hipLaunchKernelGGL(k_bin_visits16, dim3((Sl + 1) / 2), dim3(kBinThreads), 0, st, reinterpret_cast<const uint16_t *>(a.visits),
+                                       a.visit_stride, Sl, ws.ctl, launch & 3, hist, p->rows, p->cols, a.vcap, a.v16_offset, a.it_base);
+                else if (hist_t)
                     hipLaunchKernelGGL(k_bin_visits, dim3(Sl), dim3(kBinThreads), 0, st, a.visits, a.visit_stride,
                                        ws.ctl, launch & 3, hist_t, p->cols, p->rows, a.vcap);
                 else
