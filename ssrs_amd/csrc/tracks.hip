@@ -1254,12 +1254,12 @@ __device__ __forceinline__ void split_cell(uint32_t c, uint32_t cols, double inv
 //     T1 = round(2^16 a / (a + b + c)),   T2 = round(2^16 (a + b) / (a + b + c))   (a b c in ascending k,
 //     both clamped to 65535)
 // and a step is: one 4-byte gather, two integer subtractions from the top 16 bits of the uniform,
-// two sign bits -> the chosen cell.  |T - 2^16 cdf_k/cdf_8| <= 0.52 (rounding 0.5; the builder's
-// reciprocal estimates and f32 packing 2e-7 relative; the reference's normalise-twice sequence
+// two sign bits -> the chosen cell.  |T - 2^16 cdf_k/cdf_8| <= 0.55 (rounding 0.5; the builder's
+// f32 arithmetic 6e-7 relative = 0.04 units; the reference's normalise-twice sequence
 // 1e-15; the clamp only matters where
 // the uniform's top bits are 65534 / 65535, which the band covers) and the uniform's top 16 bits
 // ufi satisfy ufi <= 2^16 u < ufi + 1, so ufi - T >= 1 means cdf_k/cdf_8 <= u and ufi - T <= -2
-// means it is not (0.48 units of margin either way): the decision is the reference's unless ufi - T is -1 or 0 (3e-5 per boundary),
+// means it is not (0.45 units of margin either way): the decision is the reference's unless ufi - T is -1 or 0 (3e-5 per boundary),
 // where the exact sequence on the raw windows decides.  Everything irregular is an entry with
 // T1 > T2 (impossible otherwise): T1 = 0xFFFF and T2 =
 //   0  poisoned row    (a NaN / infinite weight: exact sequence, movmodel.py:228-230)
@@ -1286,13 +1286,6 @@ __host__ __device__ constexpr int thr_plane_shift(int rows, int cols)
     return sh;
 }
 
-// 1 / x as the hardware estimates it: v_rcp_f64 is good to 4.6e-8 on gfx950 (tools/microbench/rcp.hip),
-// 0.003 units of a 16-bit threshold (inf / NaN / 0 propagate as such)
-__device__ __forceinline__ double fast_rcp(double x)
-{
-    return __builtin_amdgcn_rcp(x);
-}
-
 __host__ __device__ __forceinline__ uint32_t thr_pack(double b1, double b2)
 {   // two boundaries in [0, 1] -> T1 | T2 << 16 (f32 is plenty: 24 bits against 16)
     const float t1 = static_cast<float>(b1) * 65536.0f + 0.5f, t2 = static_cast<float>(b2) * 65536.0f + 0.5f;   // round half up
@@ -1308,14 +1301,30 @@ struct ThrPrior {
     uint32_t thr9[9];        // thresholds of the unmasked prior (2^16 units, clamped), k = 0..8
 };
 
+// The builder works in f32 throughout: a threshold only has to land within 0.45 units of 2^-16
+// of the reference's boundary (the band above), i.e. 7e-6 in probability, and an f32 weight is
+// good to 3e-7 relative (v_rcp_f32 is 1 ulp).  What f32 cannot represent goes to the exact
+// sequence instead (a poisoned entry):
+//   * an updraft above 1e20 (v_rcp_f32 flushes denormal results): its reciprocal is staged as NaN,
+//     which poisons the nine cells around it;
+//   * a NaN / infinite weight anywhere in the window (the reference's own rule for NaN,
+//     movmodel.py:228-230; f32 overflow joins it): the sum of the eight raw weights is not finite;
+//   * a row whose total leaves [1e-30, 1e30] (denormal weights have large RELATIVE errors; the
+//     reciprocal of a huge total is flushed).
+// Staged reciprocals carry a factor 2^-24, so that a weight 2^24 d / (1/u_c + 1/u_q) with d > 0
+// never underflows to zero (>= 8.4 x 1.4e-45): "all three weights are zero" is `tot == 0`, as in
+// f64.  The common factor drops out of the thresholds.
+// No branches and ~190 vector instructions per cell: a wave64 instruction occupies its SIMD for
+// four clocks, so the first version's 365 (+ 45 branches, one per case of every row) took 300 us
+// whatever the loads and stores did (probe builds SSRS_PROBE_K2A_*).  v_cvt_pknorm_u16_f32 packs
+// both thresholds in one instruction (round(65535 x), saturating: x carries 65536 / 65535).
+template <bool HASPOT>
 __global__ __launch_bounds__(kBlock) void k_transition_thr(
     const double *__restrict__ updraft, const float *__restrict__ potential,
     uint32_t *__restrict__ table_out, int rows, int cols, int tiles_x, int ntiles, const ThrPrior pr, int plane_shift)
 {
-    // staging as k_transition_table: clipped reciprocals and potential of the tile + halo
     constexpr int LW = kTabW + 2, LH = kTabH + 2;
-    __shared__ double s_inv[LW * LH];
-    __shared__ float s_pot[LW * LH];
+    __shared__ float2 s_cell[LW * LH];                       // x: 2^-24 / clipped updraft, y: potential
     const int t = xcd_band(blockIdx.x, ntiles);
     const int r0 = (t / tiles_x) * kTabH, c0 = (t % tiles_x) * kTabW;
     for (int i = threadIdx.x; i < LW * LH; i += kBlock) {
@@ -1324,69 +1333,75 @@ __global__ __launch_bounds__(kBlock) void k_transition_thr(
         gr = gr < 0 ? 0 : (gr >= rows ? rows - 1 : gr);
         gc = gc < 0 ? 0 : (gc >= cols ? cols - 1 : gc);
         const size_t g = static_cast<size_t>(gr) * cols + gc;
-        const double v = updraft[g];
-        const double w = v != v ? v : (v > 1e-06 ? v : 1e-06);
-        // the thresholds are rounded to f32 and guarded by a band of 1e-7: the weights need no
-        // correctly rounded divisions here (the exact sequence of the stepper has its own),
-        // a reciprocal with one Newton step (~1e-16) does
-        s_inv[i] = fast_rcp(w);
-        s_pot[i] = potential ? potential[g] : 0.f;
+        float2 c;
+#ifdef SSRS_PROBE_K2A_NOLOAD
+        const float v = 1.0f + (g & 255);
+        c.y = HASPOT ? 1000.f - (g & 1023) : 0.f;
+#else
+        const float v = static_cast<float>(updraft[g]);
+        c.y = HASPOT ? potential[g] : 0.f;
+#endif
+        const float w = fmaxf(v, 1e-06f);                    // clip(min=1e-6); NaN is restored below
+        c.x = (v <= 1e20f) ? __builtin_amdgcn_rcpf(w) * 5.9604645e-08f : __builtin_nanf("");
+        s_cell[i] = c;
     }
     __syncthreads();
     const int lc = static_cast<int>(threadIdx.x % kTabW) + 1;
     const int col = c0 + lc - 1;
     if (col >= cols) return;
+    uint32_t zero_row[8];                                    // wave-uniform
+#pragma unroll
+    for (int rc = 0; rc < 8; ++rc) zero_row[rc] = ((pr.reversal >> rc) & 1u) ? kThrReversal : pr.zero_e[rc];
     for (int lr = static_cast<int>(threadIdx.x / kTabW) + 1; lr <= kTabH; lr += kBlock / kTabW) {
         const int row = r0 + lr - 1;
         if (row >= rows) break;
-        const size_t i = static_cast<size_t>(row) * cols + col;
+        const uint32_t off = (static_cast<uint32_t>(row) * static_cast<uint32_t>(cols) + static_cast<uint32_t>(col)) * 4u;   // < 2^29
         const bool interior = row > 0 && col > 0 && row < rows - 1 && col < cols - 1;
-        uint32_t o[8];
-        if (!interior) {
+        float w[9];
+        const float2 cc = s_cell[lr * LW + lc];
+        float sum = 0.f;                                     // not finite <=> some raw weight (or the centre) is not
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = kThrBoundary;
-        } else {
-            double w[9];
-            const double ic = s_inv[lr * LW + lc];
-            const float pc = s_pot[lr * LW + lc];
-            bool bad = false;
-#pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                const int q = (lr + dr_of(j)) * LW + lc + dc_of(j);
-                double v = 2.0 * fast_rcp(ic + s_inv[q]);               // harmonic mean
-                if (potential) {
-                    const float d = pc - s_pot[q];
-                    const float ninv = (j == 4) ? 0.f : ((j & 1) ? 1.f : SSRS_NINV_DIAG);
-                    const float e = d * ninv;                           // stays f32
-                    v = v * static_cast<double>(e);
-                }
-                bad |= (v - v != 0.0);                                  // inf or NaN (also the centre's)
-                w[j] = v > 0.0 ? v : 0.0;                               // clip(min=0)
+        for (int j = 0; j < 9; ++j) {
+            if (j == 4) continue;
+            const float2 cq = s_cell[(lr + dr_of(j)) * LW + lc + dc_of(j)];
+            float v = __builtin_amdgcn_rcpf(cc.x + cq.x);    // 2^23 x harmonic mean
+            if (HASPOT) {
+                const float d = cc.y - cq.y;
+                v *= (j & 1) ? d : d * SSRS_NINV_DIAG;       // d x ninv stays f32 in the reference as well
             }
-#pragma unroll
-            for (int rc = 0; rc < 8; ++rc) {
-                const uint32_t ord = ring_order(rc);
-                const int ring3[3] = {(rc + 7) % 8, rc, (rc + 1) % 8};
-                const double wa = w[kRingK[ring3[ord & 3u]]], wb = w[kRingK[ring3[(ord >> 2) & 3u]]],
-                             wc = w[kRingK[ring3[(ord >> 4) & 3u]]];
-                const double ab = wa + wb, tot = ab + wc;               // np.cumsum's order
-                uint32_t e;
-                if (bad) {
-                    e = kThrPoison;
-                } else if (!(tot > 0.0)) {
-                    e = ((pr.reversal >> rc) & 1u) ? kThrReversal : pr.zero_e[rc];
-                } else {
-                    const double r = fast_rcp(tot);
-                    const double b1 = wa * r, b2 = ab * r;
-                    e = (b2 <= 1.0000001) ? thr_pack(b1, b2) : kThrPoison;       // tot overflowed: NaN / inf
-                }
-                o[rc] = e;
-            }
+            sum += v;
+            w[j] = fmaxf(v, 0.f);                            // clip(min=0)
         }
-        // plane rc holds the entries of last move rc for all cells, 4 bytes each
+        const bool bad = !(fabsf(sum) <= 3e38f);
+        const bool ovr = bad | !interior;
+        const uint32_t ovr_e = interior ? kThrPoison : kThrBoundary;
 #pragma unroll
-        for (int rc = 0; rc < 8; ++rc)
-            *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(table_out) + (static_cast<size_t>(rc) << plane_shift) + i * 4) = o[rc];
+        for (int rc = 0; rc < 8; ++rc) {
+            const uint32_t ord = ring_order(rc);
+            const int ring3[3] = {(rc + 7) % 8, rc, (rc + 1) % 8};
+            const int ka = kRingK[ring3[ord & 3u]], kb = kRingK[ring3[(ord >> 2) & 3u]], kc = kRingK[ring3[(ord >> 4) & 3u]];
+            const float ab = w[ka] + w[kb], tot = ab + w[kc];                   // np.cumsum's order
+            const float r = __builtin_amdgcn_rcpf(tot) * 1.0000153f;            // 65536 / 65535
+            const auto pk = __builtin_amdgcn_cvt_pknorm_u16(w[ka] * r, ab * r); // T1 | T2 << 16, T1 <= T2
+            uint32_t e = __builtin_bit_cast(uint32_t, pk);
+            // as integers: 1e-30 <= tot <= 1e30 (tot >= 0 or NaN)
+            const bool fine = (__float_as_uint(tot) - 0x0DA24260u) <= (0x7149F2CAu - 0x0DA24260u);
+            e = fine ? e : kThrPoison;
+            asm volatile("" : "+v"(e));                      // or the compiler branches around the six lines above
+            e = (tot == 0.f) ? zero_row[rc] : e;
+            e = ovr ? ovr_e : e;
+            // plane rc holds the entries of last move rc for all cells, 4 bytes each
+#ifdef SSRS_PROBE_K2A_NOSTORE
+            if (e == 0x12345678u)
+#endif
+#ifdef SSRS_PROBE_K2A_PAD      // planes off the power-of-two stride (inside the slack of the last plane; timing only)
+            *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(table_out) + (static_cast<size_t>(rc) << plane_shift) - static_cast<size_t>(rc) * SSRS_PROBE_K2A_PAD + off) = e;
+#elif defined(SSRS_K2A_NT)
+            __builtin_nontemporal_store(e, reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(table_out) + (static_cast<size_t>(rc) << plane_shift) + off));
+#else
+            *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(table_out) + (static_cast<size_t>(rc) << plane_shift) + off) = e;
+#endif
+        }
     }
 }
 
@@ -2496,8 +2511,12 @@ extern "C" int ssrs_transition_thr_build(const double *updraft, const float *pot
     ThrPrior pr;
     prior_tables(prior, &pr);
     const int tx = (cols + kTabW - 1) / kTabW, ty = (rows + kTabH - 1) / kTabH, nt = tx * ty;
-    hipLaunchKernelGGL(k_transition_thr, dim3(static_cast<unsigned>(nt)), dim3(kBlock), 0, as_stream(stream),
-                       updraft, potential, reinterpret_cast<uint32_t *>(thr), rows, cols, tx, nt, pr, thr_plane_shift(rows, cols));
+    if (potential)
+        hipLaunchKernelGGL(k_transition_thr<true>, dim3(static_cast<unsigned>(nt)), dim3(kBlock), 0, as_stream(stream),
+                           updraft, potential, reinterpret_cast<uint32_t *>(thr), rows, cols, tx, nt, pr, thr_plane_shift(rows, cols));
+    else
+        hipLaunchKernelGGL(k_transition_thr<false>, dim3(static_cast<unsigned>(nt)), dim3(kBlock), 0, as_stream(stream),
+                           updraft, potential, reinterpret_cast<uint32_t *>(thr), rows, cols, tx, nt, pr, thr_plane_shift(rows, cols));
     SSRS_HIP_CHECK(hipGetLastError());
     return SSRS_OK;
 }

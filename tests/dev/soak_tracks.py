@@ -17,7 +17,7 @@ while time.time() - t0 < budget:
         rows, cols = int(rng.integers(5, 200)), int(rng.integers(1025, 2600))
     n = int(rng.choice([1, 7, 64, 65, 300, 2000, 9000, 20000]))
     dirn = float(rng.choice([0., 45., 90., 135., 180., 225., 270., 315., rng.uniform(0, 360)]))
-    kind = rng.choice(['rough', 'smooth', 'flat', 'speckle', 'nan', 'wells'])
+    kind = rng.choice(['rough', 'smooth', 'flat', 'speckle', 'nan', 'wells', 'scales'])
     if kind == 'wells' and rows * cols > 40000:               # wandering tracks run to rows / 2 * cols / 2 moves
         kind = 'rough'
     upd = np.abs(rng.normal(0.8, 0.6, (rows, cols)))
@@ -39,6 +39,11 @@ while time.time() - t0 < budget:
         pot = (ramp + rng.normal(0, rng.choice([0.01, 1.0, 30.0]), (rows, cols))).astype(np.float32)
     if kind == 'nan':
         upd[rng.random((rows, cols)) < 0.01] = np.nan
+    if kind == 'scales':                                      # every magnitude f32 has (and some it has not)
+        upd = upd * 10. ** rng.uniform(-9, 39, upd.shape)
+        upd[rng.random((rows, cols)) < 0.01] = np.inf
+        band = 10. ** rng.integers(-44, 8, rows // 8 + 1).astype(np.float64)
+        pot = (pot.astype(np.float64) * np.repeat(band, 8)[:rows, None]).astype(np.float32)
     starts = np.stack([rng.integers(0, rows, n), rng.integers(0, cols, n)], 1)
     s = int(rng.integers(0, 2**31))
     mem = int(rng.choice([1, 1, 1, 0, 2, 3, 8]))

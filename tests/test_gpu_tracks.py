@@ -712,7 +712,7 @@ def test_thr_table_g7_cases(gpu, golden, tag):
             movmodel.simulate_tracks(*args, seed=int(g['seed']), use_table=True, thr=True)
 
 
-@pytest.mark.parametrize('case', ['rough', 'nan_zero', 'updraft_only', 'tiny', 'huge', 'flat', 'south'])
+@pytest.mark.parametrize('case', ['rough', 'nan_zero', 'updraft_only', 'tiny', 'huge', 'flat', 'south', 'scales'])
 def test_thr_table_vs_c_oracle(gpu, case):
     """Fresh inputs incl. every flagged kind of row: NaN (poisoned) and all-zero rows (masked prior
     thresholds), weights below the f32 range and beyond it, a flat potential (the prior decides
@@ -736,6 +736,12 @@ def test_thr_table_vs_c_oracle(gpu, case):
         pot = (pot.astype(np.float64) * 1e30).astype(np.float32)
     elif case == 'flat':
         pot = np.full_like(pot, 7.0)
+    elif case == 'scales':                         # the f32 table builder: every magnitude in one field
+        r2 = np.random.default_rng(77)
+        upd = upd * 10. ** r2.uniform(-9, 39, upd.shape)
+        upd[r2.random(upd.shape) < 0.01] = np.inf
+        band = 10. ** r2.integers(-44, 8, rows // 10 + 1).astype(np.float64)
+        pot = (pot.astype(np.float64) * np.repeat(band, 10)[:rows, None]).astype(np.float32)
     elif case == 'south':
         dirn = 180.                                # the potential still pulls north: reversals
         pot = pot.copy()
