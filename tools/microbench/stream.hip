@@ -32,6 +32,13 @@ __global__ void k_mix(const double *u, const float *p, uint32_t *t, size_t n, si
         for (int rc = 0; rc < 8; ++rc) t[rc * plane + i] = e + rc;
     }
 }
+__global__ void k_mix_raster(const double *z, float *o, double *u, size_t n)
+{   // the raster kernel's traffic: 8 B read, 4 + 8 B written per cell
+    for (size_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+        const double v = z[i];
+        o[i] = static_cast<float>(v); u[i] = v + 1.0;
+    }
+}
 __global__ void k_pknorm(const float *x, uint32_t *o, int n)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -56,6 +63,8 @@ int main()
         float w4 = timed([&] { hipLaunchKernelGGL(k_write<uint32_t>, dim3(grid), dim3(256), 0, 0, (uint32_t *)b, bytes / 4, 7u); });
         float c16 = timed([&] { hipLaunchKernelGGL(k_copy<uint4>, dim3(grid), dim3(256), 0, 0, (const uint4 *)a, (uint4 *)b, bytes / 16); });
         float mix = timed([&] { hipLaunchKernelGGL(k_mix, dim3(grid), dim3(256), 0, 0, (const double *)a, (const float *)(a + cells * 8), (uint32_t *)b, cells, size_t(1) << 25); });
+        float mr = timed([&] { hipLaunchKernelGGL(k_mix_raster, dim3(grid), dim3(256), 0, 0, (const double *)a, (float *)b, (double *)(b + cells * 4), cells); });
+        printf("grid %6d: raster mix %.2f TB/s (20 B/cell, %.0f us)\n", grid, cells * 20.0 / mr / 1e9, mr * 1e3);
         printf("grid %6d: read x4 %.2f  read dword %.2f  write x4 %.2f  write dword %.2f  copy x4 %.2f (r+w)  table mix %.2f TB/s (44 B/cell, %.0f us)\n", grid,
                bytes / r16 / 1e9, bytes / r4 / 1e9, bytes / w16 / 1e9, bytes / w4 / 1e9, 2.0 * bytes / c16 / 1e9, cells * 44.0 / mix / 1e9, mix * 1e3);
     }
