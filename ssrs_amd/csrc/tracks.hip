@@ -584,10 +584,13 @@ __device__ __forceinline__ void plan_coords(const PlanGeom &g, int row, int col,
     perp = static_cast<int>(lrint(col * g.cos_t - row * g.sin_t)) + g.offset;
 }
 
+// sort key = perp << par_bits | par: both coordinates lie in [0, 2 offset], so rasters up to
+// ~16k x 16k sort on 32-bit keys (half the passes' traffic, one pass fewer than 40 bits)
+template <typename KeyT>
 __global__ __launch_bounds__(kBlock) void k_plan_keys(const int32_t *__restrict__ start_rc,
                                                      long long ntracks, PlanGeom g,
-                                                     unsigned long long *__restrict__ keys,
-                                                     int32_t *__restrict__ vals, TrackCtl *ctl)
+                                                     KeyT *__restrict__ keys,
+                                                     int32_t *__restrict__ vals, TrackCtl *ctl, int par_bits)
 {
     const long long t = blockIdx.x * static_cast<long long>(kBlock) + threadIdx.x;
     int par = 0x7fffffff;
@@ -596,16 +599,22 @@ __global__ __launch_bounds__(kBlock) void k_plan_keys(const int32_t *__restrict_
         plan_coords(g, start_rc[2 * t], start_rc[2 * t + 1], par, perp);
         par = par < 0 ? 0 : par;
         perp = perp < 0 ? 0 : perp;
-        keys[t] = (static_cast<unsigned long long>(perp) << 20) | static_cast<unsigned>(par & 0xFFFFF);
+        const int top = (1 << par_bits) - 1;
+        keys[t] = (static_cast<KeyT>(perp > top ? top : perp) << par_bits) | static_cast<KeyT>(par > top ? top : par);
         vals[t] = static_cast<int32_t>(t);
     }
-    // wave minimum, one atomic per wave
+    // block minimum, one atomic per block (one per wave: 1500 atomics on one word took 15 us)
+    __shared__ int s_min;
+    if (threadIdx.x == 0) s_min = 0x7fffffff;
+    __syncthreads();
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const int o = __shfl_down(par, off);
         par = o < par ? o : par;
     }
-    if ((threadIdx.x & 63) == 0 && par != 0x7fffffff) atomicMin(&ctl->par_min, static_cast<uint32_t>(par));
+    if ((threadIdx.x & 63) == 0 && par != 0x7fffffff) atomicMin(&s_min, par);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_min != 0x7fffffff) atomicMin(&ctl->par_min, static_cast<uint32_t>(s_min));
 }
 
 enum { MODE_PRIOR = 0, MODE_UPDRAFT = 1, MODE_FLUIDFLOW = 2, MODE_TABLE = 3 };
@@ -642,7 +651,7 @@ struct StepArgs {
                                  // ring position of the heading
     uint32_t vcap;               // slots per XCD list in the visit buffer (= cap, or the launch's own
                                  // bound when its visits are recorded for trajectory output)
-    const double *thr;           // [9][9] prior-fallback thresholds (k_prior_thresholds)
+    const double *thr;           // [9][9] prior-fallback thresholds (k_ctl_init)
     const uint8_t *zmask;        // ring table's zero-mask bytes (scattered variant), or NULL
     uint32_t *hist_copies;       // privatised histogram copies (scattered batches), or NULL
     int ncopies;
@@ -914,10 +923,19 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
 // thr[d * 9 + k] = cdf_k / cdf_8 for last move d, computed with the arithmetic of
 // choose_move's exact branch (same pairwise sums, same divisions), so that
 // "count of thr <= u" IS np.random.choice's pick.
-__global__ void k_prior_thresholds(const double *__restrict__ prior, double *__restrict__ thr)
+struct PriorArg { double v[9]; };
+
+// Start of a call, one kernel instead of two memsets, a copy and a threshold kernel (each of
+// those cost the stream ~6 us): clears the control block, stores the prior, par_min = max, and
+// the prior-fallback thresholds from the by-value prior.
+__global__ void k_ctl_init(TrackCtl *ctl, const PriorArg pr, double *__restrict__ thr)
 {
     const int d = threadIdx.x;
+    if (d < 32) reinterpret_cast<uint32_t *>(ctl->count)[d] = 0;
+    if (d == 32) { ctl->error = 0; ctl->par_min = 0xFFFFFFFFu; ctl->steps = 0; ctl->strays = 0; ctl->pad = 0; ctl->pad2 = 0.0; }
+    if (d < 9) ctl->prior[d] = pr.v[d];
     if (d >= 9) return;
+    const double *prior = pr.v;
     const uint32_t mask = restriction_of(static_cast<uint32_t>(d));
     double q[9];
     bool any = false;
@@ -1106,7 +1124,7 @@ __global__ __launch_bounds__(kBlock) void k_step_lean(const StepArgs a)
                     if ((ba & bb & bc) == 0x80000000u && (ba | bb | bc) == 0x80000000u) {
                         // all three admissible weights are exactly zero: the directional
                         // prior decides (movmodel.py:234-240); thresholds precomputed per
-                        // last move with the exact arithmetic (k_prior_thresholds)
+                        // last move with the exact arithmetic (k_ctl_init)
                         const double *t = a.thr + 9u * (static_cast<uint32_t>(kKOfRing >> (4 * rc)) & 0xFu);
                         int idx = 0;
 #pragma unroll
@@ -2317,7 +2335,11 @@ static size_t sort_temp_size(int64_t n)
                                        static_cast<unsigned long long *>(nullptr),
                                        static_cast<const int32_t *>(nullptr),
                                        static_cast<int32_t *>(nullptr), static_cast<int>(n), 0, 40);
-    return bytes;
+    size_t bytes32 = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes32, static_cast<const uint32_t *>(nullptr),
+                                       static_cast<uint32_t *>(nullptr), static_cast<const int32_t *>(nullptr),
+                                       static_cast<int32_t *>(nullptr), static_cast<int>(n), 0, 32);
+    return bytes > bytes32 ? bytes : bytes32;
 }
 
 static size_t workspace_layout(int64_t n, char *base, Workspace *ws)
@@ -2362,10 +2384,11 @@ static size_t workspace_layout(int64_t n, char *base, Workspace *ws)
 }
 
 // pinned host words for the live-count read-back, one set per host thread
+constexpr int kFinalSlot = 384;      // words: the read-back ring (8 slots of 40) ends at 320
 static uint32_t *pinned_counts()
 {
     static thread_local uint32_t *buf = nullptr;
-    if (!buf && hipHostMalloc(reinterpret_cast<void **>(&buf), 256 * sizeof(uint32_t)) != hipSuccess)
+    if (!buf && hipHostMalloc(reinterpret_cast<void **>(&buf), 512 * sizeof(uint32_t)) != hipSuccess)
         buf = nullptr;
     return buf;
 }
@@ -2585,12 +2608,16 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
     const int mode = table ? MODE_TABLE : (updraft ? (potential ? MODE_FLUIDFLOW : MODE_UPDRAFT)
                                                    : MODE_PRIOR);
 
-    SSRS_HIP_CHECK(hipMemsetAsync(ws.ctl, 0, sizeof(TrackCtl), st));
-    SSRS_HIP_CHECK(hipMemcpyAsync(ws.ctl->prior, p->prior, 9 * sizeof(double), hipMemcpyHostToDevice, st));
     hipEvent_t ev_first = nullptr, ev_last = nullptr;
     SSRS_HIP_CHECK(hipEventCreate(&ev_first));
     SSRS_HIP_CHECK(hipEventCreate(&ev_last));
     SSRS_HIP_CHECK(hipEventRecord(ev_first, st));
+    {
+        PriorArg pa;
+        for (int k = 0; k < 9; ++k) pa.v[k] = p->prior[k];
+        hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(64), 0, st, ws.ctl, pa, ws.thr);
+        SSRS_HIP_CHECK(hipGetLastError());
+    }
     const bool coherent = (p->flags & SSRS_TRACKS_NO_SCHEDULE) == 0;
     PlanGeom geom = {};
     {
@@ -2604,14 +2631,24 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
             geom.cos_t = nrm > 0.0 ? vr / nrm : 1.0;
             geom.sin_t = nrm > 0.0 ? vc / nrm : 0.0;
             geom.offset = p->rows + p->cols;
-            SSRS_HIP_CHECK(hipMemsetAsync(&ws.ctl->par_min, 0xFF, sizeof(uint32_t), st));
-            hipLaunchKernelGGL(k_plan_keys, dim3(blocks), dim3(kBlock), 0, st, start_rc,
-                               static_cast<long long>(ntracks), geom, ws.keys[0], ws.list[1], ws.ctl);
-            SSRS_HIP_CHECK(hipGetLastError());
+            int par_bits = 1;
+            while ((1ll << par_bits) <= 2ll * geom.offset) ++par_bits;       // <= 18 (rows, cols <= 32767)
             size_t temp_bytes = ws.sort_temp_bytes;
-            SSRS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(
-                ws.sort_temp, temp_bytes, ws.keys[0], ws.keys[1], ws.list[1], ws.list[0],
-                static_cast<int>(ntracks), 0, 40, st));
+            if (2 * par_bits <= 32) {
+                uint32_t *k0 = reinterpret_cast<uint32_t *>(ws.keys[0]), *k1 = reinterpret_cast<uint32_t *>(ws.keys[1]);
+                hipLaunchKernelGGL(k_plan_keys<uint32_t>, dim3(blocks), dim3(kBlock), 0, st, start_rc,
+                                   static_cast<long long>(ntracks), geom, k0, ws.list[1], ws.ctl, par_bits);
+                SSRS_HIP_CHECK(hipGetLastError());
+                SSRS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(
+                    ws.sort_temp, temp_bytes, k0, k1, ws.list[1], ws.list[0], static_cast<int>(ntracks), 0, 2 * par_bits, st));
+            } else {
+                hipLaunchKernelGGL(k_plan_keys<unsigned long long>, dim3(blocks), dim3(kBlock), 0, st, start_rc,
+                                   static_cast<long long>(ntracks), geom, ws.keys[0], ws.list[1], ws.ctl, par_bits);
+                SSRS_HIP_CHECK(hipGetLastError());
+                SSRS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(
+                    ws.sort_temp, temp_bytes, ws.keys[0], ws.keys[1], ws.list[1], ws.list[0],
+                    static_cast<int>(ntracks), 0, 2 * par_bits, st));
+            }
         }
         hipLaunchKernelGGL(k_tracks_init, dim3(blocks), dim3(kBlock), 0, st, start_rc,
                            static_cast<long long>(ntracks), p->rows, p->cols, hist, traj,
@@ -2633,7 +2670,6 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
     a.coherent = coherent ? 1 : 0;
     a.cap = ws.cap;
     a.thr = ws.thr;
-    hipLaunchKernelGGL(k_prior_thresholds, dim3(1), dim3(64), 0, st, ws.ctl->prior, ws.thr);
     a.vcap = ws.cap;
     const bool lean = p->memory_parameter == 1 && traj == nullptr;
     const bool ring = (p->flags & SSRS_TRACKS_RING_TABLE) != 0;
@@ -2712,9 +2748,27 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
     // is copied back asynchronously and examined while the next batch runs, so
     // the GPU never waits on the host.  Launches past the end see count 0.
     constexpr int kBatch = 2, kRing = 8;
-    hipEvent_t ev_batch[kRing];
-    for (int i = 0; i < kRing; ++i) SSRS_HIP_CHECK(hipEventCreate(&ev_batch[i]));
-    std::vector<hipEvent_t> ev_prof, ev_bin, ev_hist;   // launch starts / ends; binning kernel brackets
+    constexpr int kSlotWords = 40;           // 160 bytes of TrackCtl: counts .. strays
+    static_assert(offsetof(TrackCtl, strays) + sizeof(unsigned long long) <= kSlotWords * sizeof(uint32_t), "read-back slot");
+    int slot_row[kRing] = {};
+    // (profile mode: every batch gets its own event, which is also the start mark of the next launch)
+    hipEvent_t ev_batch[kRing] = {};
+    if (!profile)
+        for (int i = 0; i < kRing; ++i) SSRS_HIP_CHECK(hipEventCreate(&ev_batch[i]));
+    // SSRS_TRACKS_PROFILE: ONE event per boundary (an event record costs the stream ~5 us): a stepper
+    // launch runs from the mark before it to its own mark (kind 1), its binning kernels from there to
+    // theirs (kind 2); an explicit start mark (kind 0) only where something else was queued in between
+    std::vector<hipEvent_t> ev_marks;
+    std::vector<int> mark_kind;
+    bool marks_adjacent = false;             // the last mark is the start of whatever is queued next
+    auto mark = [&](int kind) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        (void)hipEventRecord(e, st);
+        ev_marks.push_back(e);
+        mark_kind.push_back(kind);
+        marks_adjacent = true;
+    };
     int launch = 0;
     long long it_done = 0;                   // threshold stepper: iterations of the launches so far (after the first move)
     bool want_rebalance = false;
@@ -2725,7 +2779,7 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
     a.v16_offset = geom.offset;
     // bound on the longest XCD list
     uint32_t upper = static_cast<uint32_t>(ntracks < static_cast<int64_t>(ws.cap) ? ntracks : ws.cap);
-    int batches = 0, checked = 0, judge_from = 0;
+    int batches = 0, checked = 0, judge_from = 0, last_Sl = 0;
     int window_launches = 0, tile_launches = 0;
     bool finished = false;
     int rc = SSRS_OK;
@@ -2736,11 +2790,15 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
             // pseudo-launch: list[launch & 1] -> list[(launch + 1) & 1], counts likewise
             hipLaunchKernelGGL(k_rebalance_lists, dim3(1), dim3(1024), 0, st, ws.list[launch & 1], ws.list[(launch + 1) & 1],
                                ws.ctl, launch & 3, (launch + 1) & 3, (launch + 2) & 3, ws.cap);
+            marks_adjacent = false;
             ++launch;
             want_rebalance = false;
             rebalance_cooldown = 3;
         }
-        for (int j = 0; j < kBatch; ++j, ++launch) {
+        // one launch per batch while launches are long and few (the host then sees the batch die one
+        // launch earlier: one empty launch at the end of a short run instead of two); two otherwise
+        const int depth = (thr && last_Sl >= 512 && launch < 24) ? 1 : kBatch;
+        for (int j = 0; j < depth; ++j, ++launch) {
             a.launch = launch;
             a.list_in = (launch == 0 && !coherent) ? nullptr : ws.list[launch & 1];
             a.list_out = ws.list[(launch + 1) & 1];
@@ -2779,6 +2837,7 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                     break;
                 }
                 copies_live = true;
+                marks_adjacent = false;
                 a.hist_copies = copies_ptr;
                 a.ncopies = ncopies;
             }
@@ -2819,16 +2878,14 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                                                                 hipMemcpyDeviceToDevice, st);
                     if (e1 != hipSuccess || e2 != hipSuccess) { rc = set_error(SSRS_ERR_HIP, "trajectory record copy failed"); break; }
                     rec->chunks.push_back(ch);
+                    marks_adjacent = false;
                     a.visits = const_cast<uint32_t *>(ch.visits);
                     a.visit_stride = static_cast<long long>(kXcd) * vcap;
                     a.vcap = vcap;
                     rec_counts = ch.counts;
                 }
             }
-            if (profile) {
-                hipEvent_t e;
-                if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); ev_prof.push_back(e); }
-            }
+            if (profile && !marks_adjacent) mark(0);
             // 16-bit visit keys: north-bound front through the row window, nothing recorded
             const bool v16 = thr && bin_window && a.visits == ws.visits && a.pf_dir == 1 && !hist_t && v16_ok;
             switch (first_move ? mode0 : mode) {
@@ -2862,14 +2919,9 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
             case MODE_UPDRAFT: hipLaunchKernelGGL(k_step_tracks<MODE_UPDRAFT>, dim3(blocks), dim3(kBlock), 0, st, a); break;
             default: hipLaunchKernelGGL(k_step_tracks<MODE_PRIOR>, dim3(blocks), dim3(kBlock), 0, st, a); break;
             }
-            if (profile) {      // end of the stepper launch
-                hipEvent_t e;
-                if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); ev_bin.push_back(e); }
-            }
+            if (profile) mark(1);      // end of the stepper launch
             if (bin_window) {
                 ++window_launches;
-                hipEvent_t b0 = nullptr, b1 = nullptr;
-                if (profile && hipEventCreate(&b0) == hipSuccess) (void)hipEventRecord(b0, st);
                 if (v16)
                     hipLaunchKernelGGL(k_bin_visits16, dim3((Sl + 1) / 2), dim3(kBinThreads), 0, st, reinterpret_cast<const uint16_t *>(a.visits),
                                        a.visit_stride, Sl, ws.ctl, launch & 3, hist, p->rows, p->cols, a.vcap, a.v16_offset, a.it_base);
@@ -2879,16 +2931,10 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                 else
                     hipLaunchKernelGGL(k_bin_visits, dim3(Sl), dim3(kBinThreads), 0, st, a.visits, a.visit_stride,
                                        ws.ctl, launch & 3, hist, p->rows, p->cols, a.vcap);
-                if (profile && b0 && hipEventCreate(&b1) == hipSuccess) {
-                    (void)hipEventRecord(b1, st);
-                    ev_hist.push_back(b0);
-                    ev_hist.push_back(b1);
-                }
+                if (profile) mark(2);
             }
             if (bin_tiles) {
                 ++tile_launches;
-                hipEvent_t b0 = nullptr, b1 = nullptr;
-                if (profile && hipEventCreate(&b0) == hipSuccess) (void)hipEventRecord(b0, st);
                 const double inv_cols = 1.0 / static_cast<double>(p->cols);
                 const uint32_t ucols = static_cast<uint32_t>(p->cols), ucell = static_cast<uint32_t>(ncell);
                 (void)hipMemsetAsync(ws.tile_count, 0, sizeof(uint32_t) * ntiles, st);
@@ -2906,47 +2952,56 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                 hipLaunchKernelGGL(k_bin_bucket, dim3(items), dim3(kTileThreads), 0, st, ws.bucket, ws.tile_start,
                                    ws.tile_count, ws.ctl, hist, static_cast<uint32_t>(p->rows), ucols, inv_cols, ntc,
                                    ntiles, ws.item_start);
-                if (profile && b0 && hipEventCreate(&b1) == hipSuccess) {
-                    (void)hipEventRecord(b1, st);
-                    ev_hist.push_back(b0);
-                    ev_hist.push_back(b1);
-                }
+                if (profile) mark(2);
             }
-            if (rec_counts && hist && !bin_window && !bin_tiles)      // recorded launch outside both binning paths
+            if (rec_counts && hist && !bin_window && !bin_tiles) {    // recorded launch outside both binning paths
                 hipLaunchKernelGGL(k_count_visits, dim3(blocks), dim3(kBlock), 0, st, a.visits, a.vcap, Sl, rec_counts, hist,
                                    static_cast<uint32_t>(ncell));
+                marks_adjacent = false;
+            }
             a.vis_r = keep_r;
             a.vis_c = keep_c;
             if (thr && !first_move) it_done += Sl;
+            last_Sl = Sl;
             if (hipGetLastError() != hipSuccess) { rc = set_error(SSRS_ERR_HIP, "stepper launch failed"); break; }
         }
         if (rc != SSRS_OK) break;
         // survivors of this batch = input count of the next launch
         const int slot = batches % kRing;
-        // ring slot = 16 words: [8 list counts, steps (2 words), strays (2 words), -]
-        if (hipMemcpyAsync(&host_counts[16 * slot], ws.ctl->count[launch & 3], kXcd * sizeof(uint32_t),
-                           hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipMemcpyAsync(&host_counts[16 * slot + 8], &ws.ctl->steps, 2 * sizeof(unsigned long long),
-                           hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipEventRecord(ev_batch[slot], st) != hipSuccess) {
+        // ring slot = the head of the control block in one copy: [4][8] list counts, error, par_min,
+        // steps (2 words), strays (2 words); the row this batch's survivors went to is count[launch & 3]
+        bool queued = hipMemcpyAsync(&host_counts[kSlotWords * slot], ws.ctl, kSlotWords * sizeof(uint32_t),
+                                     hipMemcpyDeviceToHost, st) == hipSuccess;
+        if (queued && profile) {
+            const size_t before = ev_marks.size();
+            mark(0);
+            queued = ev_marks.size() > before;
+            if (queued) ev_batch[slot] = ev_marks.back();
+        } else if (queued) {
+            queued = hipEventRecord(ev_batch[slot], st) == hipSuccess;
+            marks_adjacent = false;
+        }
+        if (!queued) {
             rc = set_error(SSRS_ERR_HIP, "live-count read-back failed");
             break;
         }
+        slot_row[slot] = launch & 3;
         ++batches;
         // examine every batch but the one just queued (it keeps the GPU busy)
         while (checked < batches - 1) {
             const int cs = checked % kRing;
             if (hipEventSynchronize(ev_batch[cs]) != hipSuccess) { rc = set_error(SSRS_ERR_HIP, "event sync failed"); break; }
             uint32_t c = 0;                         // longest list
-            for (int x = 0; x < kXcd; ++x) c = host_counts[16 * cs + x] > c ? host_counts[16 * cs + x] : c;
+            const uint32_t *cnt = &host_counts[kSlotWords * cs + kXcd * slot_row[cs]];
+            for (int x = 0; x < kXcd; ++x) c = cnt[x] > c ? cnt[x] : c;
             unsigned long long tot[2];
-            memcpy(tot, &host_counts[16 * cs + 8], sizeof(tot));
+            memcpy(tot, &host_counts[kSlotWords * cs + offsetof(TrackCtl, steps) / sizeof(uint32_t)], sizeof(tot));
             ++checked;
             if (c == 0) { finished = true; break; }
             upper = c;   // the live count only shrinks; a stale bound is safe
             if (thr && may_rebalance) {
                 uint32_t total = 0;
-                for (int x = 0; x < kXcd; ++x) total += host_counts[16 * cs + x];
+                for (int x = 0; x < kXcd; ++x) total += cnt[x];
                 if (rebalance_cooldown > 0) --rebalance_cooldown;
                 else if (c >= 1024 && 5ull * c >= static_cast<unsigned long long>(total) + 64ull) want_rebalance = true;   // longest list >= 1.6 x the mean
             }
@@ -2988,19 +3043,15 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
     if (hist_t && rc == SSRS_OK)
         hipLaunchKernelGGL(k_transpose_add, dim3(static_cast<unsigned>(((p->rows + 31) / 32) * ((p->cols + 31) / 32))),
                            dim3(kBlock), 0, st, hist_t, p->rows, p->cols, hist);
-    if (profile) {
-        hipEvent_t e;
-        if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); ev_prof.push_back(e); }
-    }
     (void)hipEventRecord(ev_last, st);
     // fetch step total + error flag
     TrackCtl host_ctl = {};
     if (rc == SSRS_OK) {
-        if (hipMemcpyAsync(&host_counts[128], ws.ctl, sizeof(TrackCtl), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        if (hipMemcpyAsync(&host_counts[kFinalSlot], ws.ctl, sizeof(TrackCtl), hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess)
             rc = set_error(SSRS_ERR_HIP, "final read-back failed");
         else
-            memcpy(&host_ctl, &host_counts[128], sizeof(TrackCtl));
+            memcpy(&host_ctl, &host_counts[kFinalSlot], sizeof(TrackCtl));
     } else {
         (void)hipStreamSynchronize(st);
     }
@@ -3012,21 +3063,18 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, ev_first, ev_last) == hipSuccess) stats->wall_ms = ms;
         if (profile) {
-            // stepper launch i: ev_prof[i] -> ev_bin[i]; binning kernels (side stream,
-            // overlapped with the next launch): ev_hist[2j] -> ev_hist[2j+1]
             float sum = 0.f, hsum = 0.f;
-            for (size_t i = 0; i < ev_bin.size() && i < ev_prof.size(); ++i)
-                if (hipEventElapsedTime(&ms, ev_prof[i], ev_bin[i]) == hipSuccess) sum += ms;
-            for (size_t i = 0; i + 1 < ev_hist.size(); i += 2)
-                if (hipEventElapsedTime(&ms, ev_hist[i], ev_hist[i + 1]) == hipSuccess) hsum += ms;
+            for (size_t i = 1; i < ev_marks.size(); ++i) {
+                if (mark_kind[i] == 0 || hipEventElapsedTime(&ms, ev_marks[i - 1], ev_marks[i]) != hipSuccess) continue;
+                if (mark_kind[i] == 1) sum += ms; else hsum += ms;
+            }
             stats->kernel_ms = sum;
             stats->hist_ms = hsum;
         }
     }
-    for (hipEvent_t e : ev_prof) (void)hipEventDestroy(e);
-    for (hipEvent_t e : ev_bin) (void)hipEventDestroy(e);
-    for (hipEvent_t e : ev_hist) (void)hipEventDestroy(e);
-    for (int i = 0; i < kRing; ++i) (void)hipEventDestroy(ev_batch[i]);
+    for (hipEvent_t e : ev_marks) (void)hipEventDestroy(e);
+    if (!profile)
+        for (int i = 0; i < kRing; ++i) (void)hipEventDestroy(ev_batch[i]);
     (void)hipEventDestroy(ev_first);
     (void)hipEventDestroy(ev_last);
     if (rc != SSRS_OK) return rc;
