@@ -1317,6 +1317,9 @@ struct ThrPrior {
     uint32_t zero_e[8];      // entry of the masked prior after last move rc
     uint32_t reversal;       // bit rc: the masked prior is all zero as well
     uint32_t thr9[9];        // thresholds of the unmasked prior (2^16 units, clamped), k = 0..8
+    // the unmasked prior's cells are the three admissible ones after a move rev_rc (a cosine lobe
+    // along a raster axis): a reversal row is then an ordinary row of last move rev_rc with entry rev_e
+    uint32_t rev_ok, rev_rc, rev_e;
 };
 
 // The builder works in f32 throughout: a threshold only has to land within 0.45 units of 2^-16
@@ -1429,7 +1432,13 @@ __global__ __launch_bounds__(kBlock) void k_transition_thr(
 //   hist / its private copies, 4 visit buffer with 16-bit keys relative to the front's row
 //   (north-bound fronts: a visit is its offset from cell (first start row + iteration - 1, 0);
 //   halves what the stepper writes and k_bin_visits16 reads; a visit out of that range is
-//   counted by the lane itself)
+//   counted by the lane itself), 6 a histogram window of the block in LDS (wandering tracks: on
+//   the solved 10 m field 44 % of a batch ends up roaming two basins of ~130 x 210 cells until
+//   max_moves, 1.8e8 visits per launch onto ~12 000 cells; per-step global atomics queue up on
+//   those few lines and per-lane caches of a few cells never hit.  The host sorts the live tracks
+//   by 64 x 64 tile (k_wander_keys), so a block's 256 tracks share a basin; the block counts into
+//   a kWinRows x kWinCols window around them with LDS atomics and flushes the non-zero cells once
+//   per launch; a visit outside the window is a global atomic and a stray)
 // The fifth wave of a block (PF): the batch moves as a front, so every step touches table rows no
 // one has loaded yet and 4 of 5 gathers contain a lane that waits for HBM (87 % of the L2 requests
 // hit, but a 12-line gather waits for its slowest line).  A wave cannot prefetch for itself --
@@ -1519,9 +1528,25 @@ __device__ __forceinline__ void thr_prefetch_wave(const PfArgs a, uint32_t xcd, 
     if (acc == 0x9E3779B9u && a.steps < 0) a.ctl->pad = 1;      // keeps the loads alive
 }
 
-template <int HM, bool PF = false>
+constexpr int kWinRows = 144, kWinCols = 256;      // 144 KB of LDS: one block per CU
+
+// REV: reversal rows decided in the fast path (ThrPrior::rev_*).  In the basins of a solved field a
+// track falls to the bottom of a pit (a move south, say), finds every way on uphill and the masked
+// prior empty, takes the unmasked prior's move north and falls back: every other step is a reversal,
+// and as a flag entry each one sent its whole wave through the slow path (1030 issue clocks per
+// wave-step against 490 on the ramp).  Three more instructions on the chain: variants without the
+// prefetch wave only.
+template <int HM, bool PF = false, bool REV = false>
 __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const StepArgs a, const ThrPrior pr)
 {
+    static_assert(!(HM == 6 && PF), "the block window is for batches without a front");
+    __shared__ uint32_t s_win[HM == 6 ? kWinRows * kWinCols : 1];
+    __shared__ int s_box[4];
+    if (HM == 6) {
+        for (int q = threadIdx.x; q < kWinRows * kWinCols; q += kBlock) s_win[q] = 0u;
+        if (threadIdx.x == 0) { s_box[0] = s_box[1] = 0x7fffffff; s_box[2] = s_box[3] = -1; }
+        __syncthreads();
+    }
     TrackCtl *ctl = a.ctl;
     const int in_slot = a.launch & 3, out_slot = (a.launch + 1) & 3;
     const uint32_t xcd = blockIdx.x % kXcd;
@@ -1541,7 +1566,7 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
     const uint32_t i = xcd * a.cap + il;
     const uint32_t iv = xcd * a.vcap + il;
     if (blockIdx.x == 0 && threadIdx.x < kXcd) ctl->count[(a.launch + 2) & 3][threadIdx.x] = 0;
-    if ((il & ~63u) >= nlive) return;
+    if (HM != 6 && (il & ~63u) >= nlive) return;          // (HM 6: every wave meets the block's barriers)
 
     bool live0 = il < nlive;
     const int32_t t = live0 ? (a.list_in ? a.list_in[i] : static_cast<int32_t>(i)) : 0;
@@ -1550,6 +1575,40 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
     uint32_t rc = static_cast<uint32_t>(kRingOfK >> (4 * (s.dirs & 0xFu))) & 0xFu;
     // (every track has made its first move before the first launch of this kernel: rc < 8)
     live0 = live0 && s.k >= 0 && rc < 8u;
+    // HM 6: the window is centred on the bounding box of the block's tracks
+    int wr = 0, wc = 0, win_r0 = 0, win_c0 = 0;
+    uint32_t win_stray = 0;
+    if (HM == 6) {
+        const int row0 = s.pos & 0xFFFF, col0 = (s.pos >> 16) & 0xFFFF;
+        int r_lo = live0 ? row0 : 0x7fffffff, r_hi = live0 ? row0 : -1, c_lo = live0 ? col0 : 0x7fffffff, c_hi = live0 ? col0 : -1;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            int o = __shfl_xor(r_lo, off); r_lo = o < r_lo ? o : r_lo;
+            o = __shfl_xor(r_hi, off); r_hi = o > r_hi ? o : r_hi;
+            o = __shfl_xor(c_lo, off); c_lo = o < c_lo ? o : c_lo;
+            o = __shfl_xor(c_hi, off); c_hi = o > c_hi ? o : c_hi;
+        }
+        if ((threadIdx.x & 63) == 0 && r_hi >= 0) {
+            atomicMin(&s_box[0], r_lo); atomicMin(&s_box[1], c_lo);
+            atomicMax(&s_box[2], r_hi); atomicMax(&s_box[3], c_hi);
+        }
+        __syncthreads();
+        const bool fits = s_box[2] - s_box[0] < kWinRows && s_box[3] - s_box[1] < kWinCols;
+        __syncthreads();
+        if (!fits && threadIdx.x == 0) {
+            // a block that straddles two basins (or drags a straggler): the first wave's box decides
+            // (after the host's sort the block is a run of the tile order)
+            s_box[0] = r_lo; s_box[1] = c_lo; s_box[2] = r_hi; s_box[3] = c_hi;
+        }
+        __syncthreads();
+        if (s_box[2] >= 0) {
+            // centred; a box still larger than the window: its middle
+            win_r0 = (s_box[0] + s_box[2] + 1 - kWinRows) / 2;
+            win_c0 = (s_box[1] + s_box[3] + 1 - kWinCols) / 2;
+        }
+        wr = row0 - win_r0;
+        wc = col0 - win_c0;
+    }
     const uint32_t ucols = static_cast<uint32_t>(a.cols), urows = static_cast<uint32_t>(a.rows);
     const uint32_t ncell = urows * ucols;
     uint32_t cell = __umul24(static_cast<uint32_t>(s.pos & 0xFFFF), ucols) + (static_cast<uint32_t>(s.pos >> 16) & 0xFFFFu);
@@ -1606,8 +1665,14 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
             w0 = pend_a; w1 = pend_b;
         }
         const uint32_t ufi = w0 >> 16;                               // top 16 bits of u
-        const int32_t d1 = static_cast<int32_t>(ufi) - static_cast<int32_t>(e & 0xFFFFu);
-        const int32_t d2 = static_cast<int32_t>(ufi) - static_cast<int32_t>(e >> 16);
+        uint32_t eu = e, rcd = rc;
+        if (REV && !burn) {
+            const bool rev = e == kThrReversal;
+            eu = rev ? pr.rev_e : e;
+            rcd = rev ? pr.rev_rc : rc;
+        }
+        const int32_t d1 = static_cast<int32_t>(ufi) - static_cast<int32_t>(eu & 0xFFFFu);
+        const int32_t d2 = static_cast<int32_t>(ufi) - static_cast<int32_t>(eu >> 16);
         // ufi - T in {-1, 0}: the uniform is within rounding of a boundary; T1 > T2 (d1 < d2): a flag entry
         bool special = (static_cast<uint32_t>(d1 + 1) < 2u) | (static_cast<uint32_t>(d2 + 1) < 2u) | (d1 < d2);
         if (burn) {
@@ -1615,9 +1680,9 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
             special = special | (zone & (it <= it_burn));
         }
         special = special & (stm != 0u);
-        const uint32_t ord = static_cast<uint32_t>(kRingOrder >> __umul24(6u, rc)) & 63u;
+        const uint32_t ord = static_cast<uint32_t>(kRingOrder >> __umul24(6u, rcd)) & 63u;
         const uint32_t neg = (static_cast<uint32_t>(d1) >> 31) + (static_cast<uint32_t>(d2) >> 31);     // 2 - sel
-        uint32_t nc = (rc + 7u + ((ord >> (4u - 2u * neg)) & 3u)) & 7u;
+        uint32_t nc = (rcd + 7u + ((ord >> (4u - 2u * neg)) & 3u)) & 7u;
         uint32_t base = cell, base_col = colv;
         const uint32_t cell_before = cell;
         uint32_t go = stm;
@@ -1662,6 +1727,7 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
                     nc = static_cast<uint32_t>(kRingOfK >> (4 * idx)) & 0xFu;
                     base = __umul24(static_cast<uint32_t>(er), ucols) + static_cast<uint32_t>(ec);
                     base_col = static_cast<uint32_t>(ec);
+                    if (HM == 6) { wr += er - static_cast<int>(r); wc += ec - static_cast<int>(c); }      // the nudge
                 }
             }
         }
@@ -1688,6 +1754,16 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
             vrow += a.visit_stride;
         } else if (HM == 3) {
             atomicAdd(&hbase[cell], go & 1u);
+        } else if (HM == 6) {
+            wr += static_cast<int>((dr - 1u) & go);                    // go is 0 or all ones
+            wc += static_cast<int>((dc - 1u) & go);
+            const bool inside = (static_cast<uint32_t>(wr) < static_cast<uint32_t>(kWinRows)) &
+                                (static_cast<uint32_t>(wc) < static_cast<uint32_t>(kWinCols));
+            if (go != 0u && inside) atomicAdd(&s_win[wr * kWinCols + wc], 1u);     // ds_add_u32, nothing returned
+            const bool out = (go != 0u) & !inside;
+            if (__builtin_expect(__any(out), 0)) {
+                if (out) { atomicAdd(&a.hist[cell], 1u); ++win_stray; }
+            }
         } else if (HM == 4) {
             const uint32_t key = static_cast<uint32_t>(static_cast<int32_t>(cell) - vbase);
             const bool stray = (go != 0u) & (key >= 0xFFFFu);
@@ -1724,6 +1800,18 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
             vrow16 += a.visit_stride;
         }
     if (PF && (threadIdx.x & 63) == 0) atomicMax(&s_it, 0x3fffffff);   // nothing left to wait for
+    if (HM == 6) {
+        __syncthreads();
+        for (int q = threadIdx.x; q < kWinRows * kWinCols; q += kBlock) {
+            const uint32_t n = s_win[q];
+            // (cells of the window outside the raster were never counted)
+            if (n) atomicAdd(&a.hist[static_cast<uint32_t>(win_r0 + q / kWinCols) * ucols + static_cast<uint32_t>(win_c0 + q % kWinCols)], n);
+        }
+        unsigned long long ws = win_stray;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ws += __shfl_down(ws, off);
+        if ((threadIdx.x & 63) == 0 && ws) atomicAdd(&ctl->strays, ws);
+    }
 
     // a track whose span is used up is finished: it ended at the raster's edge or took max_moves
     const bool active = live0 && span != 0u && k < static_cast<int>(a.max_k);
@@ -1737,8 +1825,26 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
     const int lane = threadIdx.x & 63;
     const int nsurv = __popcll(live);
     uint32_t basei = 0;
-    if (lane == 0 && nsurv) basei = atomicAdd(&ctl->count[out_slot][xcd], static_cast<uint32_t>(nsurv));
-    basei = __shfl(basei, 0);
+    if (HM == 6) {
+        // one reservation per BLOCK, the waves in order inside it: the tracks the host sorted into
+        // this block stay one run of the next list (per-wave reservations land in arrival order and
+        // would shuffle the basins' waves into every block)
+        __shared__ uint32_t s_surv[kBlock / 64 + 1];
+        const int wv = threadIdx.x >> 6;
+        if (lane == 0) s_surv[wv] = static_cast<uint32_t>(nsurv);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tot = 0;
+            for (int q = 0; q < kBlock / 64; ++q) tot += s_surv[q];
+            s_surv[kBlock / 64] = tot ? atomicAdd(&ctl->count[out_slot][xcd], tot) : 0u;
+        }
+        __syncthreads();
+        basei = s_surv[kBlock / 64];
+        for (int q = 0; q < wv; ++q) basei += s_surv[q];
+    } else {
+        if (lane == 0 && nsurv) basei = atomicAdd(&ctl->count[out_slot][xcd], static_cast<uint32_t>(nsurv));
+        basei = __shfl(basei, 0);
+    }
     if (active) {
         const int rank = __popcll(live & ((1ull << lane) - 1ull));
         a.list_out[xcd * a.cap + basei + rank] = t;
@@ -2309,6 +2415,42 @@ __global__ __launch_bounds__(1024) void k_rebalance_lists(const int32_t *__restr
 }
 static_assert(kXcd == 8, "k_rebalance_lists deals with j & 7 / j >> 3");
 
+// Wandering batches (k_step_thr<6>): the live tracks sorted by the 64 x 64 tile they are in, then
+// dealt to the lists round-robin like k_rebalance_lists, so that a block's tracks share a basin.
+// A pseudo-launch: keys of every list slot (dead slots sort to the end), hipcub sort with the list
+// itself as the values, deal of the first `total` sorted ids.
+constexpr uint32_t kWanderDeadKey = 1u << 18;
+__global__ __launch_bounds__(kBlock) void k_wander_keys(const int32_t *__restrict__ list_in, const TrackState *__restrict__ state,
+                                                       const TrackCtl *__restrict__ ctl, int in_slot, uint32_t cap,
+                                                       uint32_t *__restrict__ keys)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= cap * kXcd) return;
+    const uint32_t x = i / cap, il = i - x * cap;
+    uint32_t key = kWanderDeadKey;
+    if (il < ctl->count[in_slot][x]) {
+        const int32_t pos = state[list_in[i]].pos;
+        key = ((static_cast<uint32_t>(pos & 0xFFFF) >> 6) << 9) | ((static_cast<uint32_t>(pos >> 16) & 0xFFFFu) >> 6);
+    }
+    keys[i] = key;
+}
+
+__global__ __launch_bounds__(1024) void k_deal_sorted(const int32_t *__restrict__ sorted, int32_t *__restrict__ list_out,
+                                                     TrackCtl *ctl, int in_slot, int out_slot, int zero_slot, uint32_t cap)
+{
+    __shared__ uint32_t s_total;
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int x = 0; x < kXcd; ++x) { run += ctl->count[in_slot][x]; ctl->count[zero_slot][x] = 0; }
+        s_total = run;
+    }
+    __syncthreads();
+    const uint32_t total = s_total;
+    for (uint32_t j = blockIdx.x * 1024u + threadIdx.x; j < total; j += gridDim.x * 1024u)
+        list_out[(j & (kXcd - 1)) * cap + (j >> 3)] = sorted[j];
+    if (blockIdx.x == 0 && threadIdx.x < kXcd) ctl->count[out_slot][threadIdx.x] = (total + kXcd - 1 - threadIdx.x) / kXcd;
+}
+
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Workspace {
@@ -2363,7 +2505,7 @@ static size_t workspace_layout(int64_t n, char *base, Workspace *ws)
         if (ws) ws->keys[i] = reinterpret_cast<unsigned long long *>(base + off);
         off = align_up(off + sizeof(unsigned long long) * static_cast<size_t>(n), 256);
     }
-    const size_t temp = n > 0 ? sort_temp_size(n) : 0;
+    const size_t temp = n > 0 ? sort_temp_size(static_cast<int64_t>(slots)) : 0;     // (the wander sort covers every slot)
     if (ws) { ws->sort_temp = base + off; ws->sort_temp_bytes = temp; }
     off = align_up(off + temp, 256);
     const long long stride = static_cast<long long>(slots);
@@ -2447,6 +2589,17 @@ static void prior_tables(const double *prior, ThrPrior *out)
     for (int k = 0; k < 9; ++k) q[k] = k == 4 ? 0.0 : prior[k];
     thresholds(q, thr);
     for (int k = 0; k < 9; ++k) out->thr9[k] = thr_pack(thr[k], thr[k]) & 0xFFFFu;
+    uint32_t support = 0;
+    for (int k = 0; k < 9; ++k) support |= (q[k] != 0.0 ? 1u : 0u) << k;
+    for (int rh = 0; rh < 8 && !out->rev_ok; ++rh) {
+        if (support == 0 || (support & ~restriction(kRingK[rh])) != 0) continue;
+        const uint32_t ord = ring_order(rh);
+        const int ring3[3] = {(rh + 7) % 8, rh, (rh + 1) % 8};
+        const int ka = kRingK[ring3[ord & 3u]], kb = kRingK[ring3[(ord >> 2) & 3u]];
+        out->rev_ok = 1;
+        out->rev_rc = static_cast<uint32_t>(rh);
+        out->rev_e = thr_pack(thr[ka], thr[kb]);
+    }
 }
 
 extern "C" int ssrs_track_params_init(SsrsTrackParams *p, int rows, int cols,
@@ -2722,6 +2875,14 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
     const bool never_scattered = (p->flags & SSRS_TRACKS_NO_SCATTERED) != 0;
     bool scattered = (p->flags & SSRS_TRACKS_SCATTERED) != 0;
     if (scattered) binning_on = tiles_on = false;
+    // threshold stepper, front outgrown the row window (tracks wander): atomics behind the per-lane
+    // visit cache instead of tile buckets (A/B switch SSRS_TRACKS_NO_VISIT_CACHE)
+    const bool cache_ok = thr && hist != nullptr && std::getenv("SSRS_TRACKS_BLOCK_WINDOW") != nullptr;
+    bool cached = cache_ok && scattered;
+    bool want_wander_sort = cached;
+    int wander_sorts = 0, wander_cooldown = 0, stable_batches = 0;
+    uint32_t prev_total = 0;
+    const bool wander_sort_ok = ntracks >= 8192;          // (the key arrays hold 2 n words >= the list slots)
     // private histogram copies live behind the regular workspace when the caller gave room
     const size_t ncell = static_cast<size_t>(p->rows) * static_cast<size_t>(p->cols);
     const size_t ws_base = align_up(ssrs_tracks_workspace_bytes(ntracks), 256);
@@ -2786,6 +2947,29 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
     // Termination: every live track either finishes or takes S moves per
     // launch and k < max_moves, so the live count reaches 0.
     while (!finished && rc == SSRS_OK) {
+        if (want_wander_sort && cached && wander_sort_ok && launch > 0) {
+            // pseudo-launch: list[launch & 1] -> sorted by tile -> list[(launch + 1) & 1]
+            const uint32_t slots = ws.cap * kXcd;
+            uint32_t *k0 = reinterpret_cast<uint32_t *>(ws.keys[0]), *k1 = reinterpret_cast<uint32_t *>(ws.keys[1]);
+            int32_t *sorted = reinterpret_cast<int32_t *>(ws.bucket);
+            hipLaunchKernelGGL(k_wander_keys, dim3((slots + kBlock - 1) / kBlock), dim3(kBlock), 0, st, ws.list[launch & 1], ws.state,
+                               ws.ctl, launch & 3, ws.cap, k0);
+            size_t temp_bytes = ws.sort_temp_bytes;
+            if (hipcub::DeviceRadixSort::SortPairs(ws.sort_temp, temp_bytes, k0, k1, ws.list[launch & 1], sorted,
+                                                   static_cast<int>(slots), 0, 19, st) != hipSuccess) {
+                rc = set_error(SSRS_ERR_HIP, "wander sort failed");
+                break;
+            }
+            hipLaunchKernelGGL(k_deal_sorted, dim3(64), dim3(1024), 0, st, sorted, ws.list[(launch + 1) & 1], ws.ctl,
+                               launch & 3, (launch + 1) & 3, (launch + 2) & 3, ws.cap);
+            ++launch;
+            ++wander_sorts;
+            want_wander_sort = false;
+            want_rebalance = false;
+            wander_cooldown = 3;
+            rebalance_cooldown = 3;
+            marks_adjacent = false;
+        }
         if (want_rebalance && launch > 0) {
             // pseudo-launch: list[launch & 1] -> list[(launch + 1) & 1], counts likewise
             hipLaunchKernelGGL(k_rebalance_lists, dim3(1), dim3(1024), 0, st, ws.list[launch & 1], ws.list[(launch + 1) & 1],
@@ -2809,7 +2993,10 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
             int Sl = first_move ? 1 : S;
             uint32_t vcap_l = ws.cap;
             long long vstride_l = ws.visit_stride;
-            if (thr && !first_move && (binning_on || tiles_on) && !(rec && rec->complete) && grow_steps) {
+            if (thr && !first_move && cached && !(rec && rec->complete) && grow_steps) {
+                // no visit buffer to fit: only the read-back interval matters
+                Sl = 8 * S;
+            } else if (thr && !first_move && (binning_on || tiles_on) && !(rec && rec->complete) && grow_steps) {
                 // Few live tracks left (the long tail of a batch; tracks that wander until max_moves):
                 // the visit buffer then holds MORE iterations of the shrunken lists, and a launch of
                 // up to 8 S steps amortises the per-launch kernels (binning, read-back) over them
@@ -2824,13 +3011,13 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                 }
             }
             if (std::getenv("SSRS_TRACKS_DEBUG") && (launch < 40 || launch % 500 == 0))
-                fprintf(stderr, "[tracks] launch %d upper %u blocks %u Sl %d binning %d tiles %d scattered %d cap %u\n", launch, upper, blocks, Sl,
-                        binning_on ? 1 : 0, tiles_on ? 1 : 0, scattered ? 1 : 0, ws.cap);
+                fprintf(stderr, "[tracks] launch %d upper %u blocks %u Sl %d binning %d tiles %d scattered %d cached %d cap %u\n", launch, upper, blocks, Sl,
+                        binning_on ? 1 : 0, tiles_on ? 1 : 0, scattered ? 1 : 0, cached ? 1 : 0, ws.cap);
             a.steps = Sl;
             a.coherent = (coherent && !first_move) ? 1 : 0;
             a.it_base = thr && launch > 0 ? it_done : 0;
             a.visits = nullptr;
-            if (!binning_on && scattered && copies_ptr && !copies_live) {
+            if (!binning_on && scattered && copies_ptr && !copies_live && !cached) {
                 // first scattered launch: zero the private copies, count into them from now on
                 if (hipMemsetAsync(copies_ptr, 0, sizeof(uint32_t) * ncell * ncopies, st) != hipSuccess) {
                     rc = set_error(SSRS_ERR_HIP, "histogram copies memset failed");
@@ -2891,18 +3078,29 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
             switch (first_move ? mode0 : mode) {
             case MODE_TABLE:
                 if (thr) {
-                    // front-shaped batches heading north / south get the prefetch wave
-                    const bool pf = a.pf_dir != 0 && a.coherent && !scattered;
+                    // front-shaped batches heading north / south get the prefetch wave; once the front has
+                    // outgrown the row window (tile buckets) it streams rows nobody reads: 7.40 -> 7.06 s
+                    // per 100k tracks on the solved 10 m field without it
+                    const bool pf = a.pf_dir != 0 && a.coherent && !scattered && !tiles_on;
                     if (v16) {
                         hipLaunchKernelGGL((k_step_thr<4, true>), dim3(blocks), dim3(kBlock + 64), 0, st, a, thr_prior);
                         break;
                     }
+                    const bool rev = thr_prior.rev_ok != 0 && std::getenv("SSRS_TRACKS_NO_REV") == nullptr;
+                    if (cached && !a.visits) {
+                        if (rev) hipLaunchKernelGGL((k_step_thr<6, false, true>), dim3(blocks), dim3(kBlock), 0, st, a, thr_prior);
+                        else hipLaunchKernelGGL((k_step_thr<6>), dim3(blocks), dim3(kBlock), 0, st, a, thr_prior);
+                        break;
+                    }
                     if (a.visits && hist_t && binning_on) hipLaunchKernelGGL((k_step_thr<2>), dim3(blocks), dim3(kBlock), 0, st, a, thr_prior);
                     else if (a.visits && pf) hipLaunchKernelGGL((k_step_thr<1, true>), dim3(blocks), dim3(kBlock + 64), 0, st, a, thr_prior);
+                    else if (a.visits && rev) hipLaunchKernelGGL((k_step_thr<1, false, true>), dim3(blocks), dim3(kBlock), 0, st, a, thr_prior);
                     else if (a.visits) hipLaunchKernelGGL((k_step_thr<1>), dim3(blocks), dim3(kBlock), 0, st, a, thr_prior);
                     else if (a.hist && pf) hipLaunchKernelGGL((k_step_thr<3, true>), dim3(blocks), dim3(kBlock + 64), 0, st, a, thr_prior);
+                    else if (a.hist && rev) hipLaunchKernelGGL((k_step_thr<3, false, true>), dim3(blocks), dim3(kBlock), 0, st, a, thr_prior);
                     else if (a.hist) hipLaunchKernelGGL((k_step_thr<3>), dim3(blocks), dim3(kBlock), 0, st, a, thr_prior);
                     else if (pf) hipLaunchKernelGGL((k_step_thr<0, true>), dim3(blocks), dim3(kBlock + 64), 0, st, a, thr_prior);
+                    else if (rev) hipLaunchKernelGGL((k_step_thr<0, false, true>), dim3(blocks), dim3(kBlock), 0, st, a, thr_prior);
                     else hipLaunchKernelGGL((k_step_thr<0>), dim3(blocks), dim3(kBlock), 0, st, a, thr_prior);
                     break;
                 }
@@ -2999,9 +3197,21 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
             ++checked;
             if (c == 0) { finished = true; break; }
             upper = c;   // the live count only shrinks; a stale bound is safe
+            uint32_t total = 0;
+            for (int x = 0; x < kXcd; ++x) total += cnt[x];
+            if (tiles_on && cache_ok && !force_tiles && a.pf_dir != 0) {
+                // a front that outgrew the row window goes through tile buckets while part of the batch
+                // still travels; once nobody finishes any more (the survivors roam their basins until
+                // max_moves) the block windows take over
+                if (prev_total != 0 && total >= prev_total - prev_total / 32 && ++stable_batches >= 2) {
+                    tiles_on = false;
+                    cached = true;
+                    want_wander_sort = true;
+                }
+                if (prev_total == 0 || total < prev_total - prev_total / 32) stable_batches = 0;
+            }
+            prev_total = total;
             if (thr && may_rebalance) {
-                uint32_t total = 0;
-                for (int x = 0; x < kXcd; ++x) total += cnt[x];
                 if (rebalance_cooldown > 0) --rebalance_cooldown;
                 else if (c >= 1024 && 5ull * c >= static_cast<unsigned long long>(total) + 64ull) want_rebalance = true;   // longest list >= 1.6 x the mean
             }
@@ -3015,7 +3225,14 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                 const unsigned long long dsteps = tot[0] - seen_steps, dstray = tot[1] - seen_strays;
                 if (checked - 1 >= judge_from && dsteps > 0 && dstray * (tiles_on ? 2 : 4) > dsteps && !force_tiles) {
                     judge_from = batches;
-                    if (binning_on && tiles_ok) {
+                    if (binning_on && cache_ok && !tiles_ok) {
+                        // the front has outgrown the row window and there are no tile buckets
+                        binning_on = false;
+                        cached = true;
+                        want_wander_sort = true;
+                        a.vis_r = static_cast<uint32_t>(p->cols);
+                        a.vis_c = 1u;
+                    } else if (binning_on && tiles_ok) {
                         // the front has outgrown the row window; its visits may still cluster
                         binning_on = false;
                         tiles_on = true;
@@ -3026,14 +3243,28 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                         a.vis_r = static_cast<uint32_t>(p->cols);
                         a.vis_c = 1u;
                         scattered = !never_scattered;      // no front any more: zero-mask variant
+                        cached = cache_ok && scattered;
+                        want_wander_sort = cached;
                     }
                 }
+            }
+            if (cached && !(binning_on || tiles_on)) {
+                // block windows: strays = visits outside them.  Tracks still on their way into a basin
+                // (or out of their block's box) show up here: sort again, a few times at most
+                const unsigned long long dsteps = tot[0] - seen_steps, dstray = tot[1] - seen_strays;
+                if (std::getenv("SSRS_TRACKS_DEBUG") && checked < 60)
+                    fprintf(stderr, "[tracks] batch %d block windows: %llu steps, %llu strays (%.3f), live %u\n", checked, dsteps, dstray,
+                            dsteps ? static_cast<double>(dstray) / static_cast<double>(dsteps) : 0.0, total);
+                if (wander_cooldown > 0) --wander_cooldown;
+                else if (dsteps > 0 && dstray * 8 > dsteps && wander_sorts < 12) want_wander_sort = true;
             }
             // batches that never binned (small, unsorted, very wide rasters) give no stray
             // signal: tracks still alive after four raster crossings are wandering
             if (!binning_on && !tiles_on && !scattered && !never_scattered &&
-                (thr ? it_done : static_cast<long long>(launch) * S) > 4ll * (p->rows + p->cols))
+                (thr ? it_done : static_cast<long long>(launch) * S) > 4ll * (p->rows + p->cols)) {
                 scattered = true;
+                if (cache_ok && !cached) { cached = true; want_wander_sort = true; }
+            }
             seen_steps = tot[0];
             seen_strays = tot[1];
         }
