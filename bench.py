@@ -185,7 +185,7 @@ def solved_leg(args, movmodel, layers, dem, starts_h, gridsize, res, seed):
         'steps_per_track_mean': float(L.mean()), 'steps_per_track_median': float(np.median(L)),
         'steps_per_track_max': int(L.max()), 'share_at_max_moves': float(np.mean(L >= mm)), 'max_moves': mm,
         'launches': o.stats['launches'], 'window_launches': o.stats['window_launches'],
-        'tile_launches': o.stats['tile_launches'],
+        'tile_launches': o.stats['tile_launches'], 'block_window_launches': o.stats['block_window_launches'],
         'solver': {'iterations': sst['iterations'], 'residual': sst['residual'], 'converged': sst['converged'],
                    'seconds': t_solve, 'rel_tol': 1e-15, 'amg_levels': sst['amg_levels']},
         'what': 'first tracks of the same start list through ssrs_potential_solve\'s field (library default '

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SSRS_VERSION 101 /* 0.1.1 */
+#define SSRS_VERSION 102 /* 0.1.2 */
 
 #define SSRS_OK 0
 #define SSRS_ERR_INVALID (-1) /* bad argument (message says which) */
@@ -189,6 +189,9 @@ typedef struct SsrsTrackStats {
                                 column window; */
     int32_t tile_launches;   /* ... through raster-tile buckets; the other launches counted
                                 in the stepper (atomics on hist or on its private copies) */
+    int32_t block_window_launches; /* ... in the stepper, into a histogram window per block in LDS
+                                (threshold table; batches whose survivors roam a few basins) */
+    int32_t wander_sorts;    /* times the live tracks were sorted into such windows */
 } SsrsTrackStats;
 
 /* Fills rows/cols/burnin/max_moves/memory/nu and zeroes the rest; `prior` must

@@ -565,6 +565,18 @@ struct alignas(16) TrackCtl {
 
 static_assert(sizeof(TrackCtl) <= 128 * sizeof(uint32_t), "final read-back slot of pinned_counts()");
 
+// block histogram windows of wandering batches (k_step_thr<6>, k_wander_windows)
+constexpr int kWinRows = 144, kWinCols = 256;      // 144 KB of LDS: one block per CU
+constexpr int kWanderWindows = 16;
+constexpr int kBinRows = kWinRows / 4, kBinCols = kWinCols / 4;
+constexpr int kWanderBins = 16384;           // 64 KB of LDS
+struct WanderWindows {
+    int32_t n;
+    int32_t r0[kWanderWindows], c0[kWanderWindows];
+};
+
+
+
 // Coherent schedule.  Tracks are independent, so the order in which lanes pick
 // them up and the global step at which each one starts are free choices that
 // cannot change any result (the uniform is keyed by track id and the track's
@@ -617,6 +629,15 @@ __global__ __launch_bounds__(kBlock) void k_plan_keys(const int32_t *__restrict_
     if (threadIdx.x == 0 && s_min != 0x7fffffff) atomicMin(&ctl->par_min, static_cast<uint32_t>(s_min));
 }
 
+__device__ __forceinline__ int wander_window_of(const WanderWindows *__restrict__ w, int n, int row, int col)
+{
+    int id = n;
+    for (int q = n - 1; q >= 0; --q)
+        if (static_cast<uint32_t>(row - w->r0[q]) < static_cast<uint32_t>(kWinRows) &&
+            static_cast<uint32_t>(col - w->c0[q]) < static_cast<uint32_t>(kWinCols)) id = q;
+    return id;
+}
+
 enum { MODE_PRIOR = 0, MODE_UPDRAFT = 1, MODE_FLUIDFLOW = 2, MODE_TABLE = 3 };
 
 struct StepArgs {
@@ -655,6 +676,7 @@ struct StepArgs {
     const uint8_t *zmask;        // ring table's zero-mask bytes (scattered variant), or NULL
     uint32_t *hist_copies;       // privatised histogram copies (scattered batches), or NULL
     int ncopies;
+    const WanderWindows *wander; // k_step_thr<6>: the windows of the last wander sort (n = 0: none yet)
     uint32_t vis_r, vis_c;       // visit key = row * vis_r + col * vis_c: (cols, 1), or (1, rows) when
                                  // the front is a column (east / west headings: transposed binning)
 };
@@ -928,9 +950,10 @@ struct PriorArg { double v[9]; };
 // Start of a call, one kernel instead of two memsets, a copy and a threshold kernel (each of
 // those cost the stream ~6 us): clears the control block, stores the prior, par_min = max, and
 // the prior-fallback thresholds from the by-value prior.
-__global__ void k_ctl_init(TrackCtl *ctl, const PriorArg pr, double *__restrict__ thr)
+__global__ void k_ctl_init(TrackCtl *ctl, const PriorArg pr, double *__restrict__ thr, WanderWindows *wander)
 {
     const int d = threadIdx.x;
+    if (d == 33) wander->n = 0;
     if (d < 32) reinterpret_cast<uint32_t *>(ctl->count)[d] = 0;
     if (d == 32) { ctl->error = 0; ctl->par_min = 0xFFFFFFFFu; ctl->steps = 0; ctl->strays = 0; ctl->pad = 0; ctl->pad2 = 0.0; }
     if (d < 9) ctl->prior[d] = pr.v[d];
@@ -1528,8 +1551,6 @@ __device__ __forceinline__ void thr_prefetch_wave(const PfArgs a, uint32_t xcd, 
     if (acc == 0x9E3779B9u && a.steps < 0) a.ctl->pad = 1;      // keeps the loads alive
 }
 
-constexpr int kWinRows = 144, kWinCols = 256;      // 144 KB of LDS: one block per CU
-
 // REV: reversal rows decided in the fast path (ThrPrior::rev_*).  In the basins of a solved field a
 // track falls to the bottom of a pit (a move south, say), finds every way on uphill and the masked
 // prior empty, takes the unmasked prior's move north and falls back: every other step is a reversal,
@@ -1569,13 +1590,15 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
     if (HM != 6 && (il & ~63u) >= nlive) return;          // (HM 6: every wave meets the block's barriers)
 
     bool live0 = il < nlive;
-    const int32_t t = live0 ? (a.list_in ? a.list_in[i] : static_cast<int32_t>(i)) : 0;
+    int32_t t = live0 ? (a.list_in ? a.list_in[i] : static_cast<int32_t>(i)) : 0;
+    if (HM == 6 && t < 0) { live0 = false; t = 0; }      // tombstone (k_deal_sorted, this kernel's own dead)
     TrackState s = {0, -1, 0, 0};
     if (live0) s = a.state[t];
     uint32_t rc = static_cast<uint32_t>(kRingOfK >> (4 * (s.dirs & 0xFu))) & 0xFu;
     // (every track has made its first move before the first launch of this kernel: rc < 8)
     live0 = live0 && s.k >= 0 && rc < 8u;
-    // HM 6: the window is centred on the bounding box of the block's tracks
+    // HM 6: the window the host's sort filled this block from; before the first sort (or for tracks
+    // outside every window) the bounding box of the block's tracks decides
     int wr = 0, wc = 0, win_r0 = 0, win_c0 = 0;
     uint32_t win_stray = 0;
     if (HM == 6) {
@@ -1594,10 +1617,27 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
         }
         __syncthreads();
         const bool fits = s_box[2] - s_box[0] < kWinRows && s_box[3] - s_box[1] < kWinCols;
+        // window of the block's first live track (all of them, after a padded deal)
+        const int nwin = a.wander->n;
+        int wid = live0 && nwin > 0 ? wander_window_of(a.wander, nwin, row0, col0) : 0x7fffffff;
+        wid = wid >= nwin ? 0x7fffffff : wid;
+        {
+            const unsigned long long lm = __ballot(wid != 0x7fffffff);
+            wid = lm ? __shfl(wid, __ffsll(static_cast<long long>(lm)) - 1) : 0x7fffffff;
+        }
+        __shared__ int s_wid[kBlock / 64];
+        if ((threadIdx.x & 63) == 0) s_wid[threadIdx.x >> 6] = wid;
         __syncthreads();
-        if (!fits && threadIdx.x == 0) {
-            // a block that straddles two basins (or drags a straggler): the first wave's box decides
-            // (after the host's sort the block is a run of the tile order)
+        wid = 0x7fffffff;
+        for (int q = kBlock / 64 - 1; q >= 0; --q) wid = s_wid[q] != 0x7fffffff ? s_wid[q] : wid;
+        if (wid != 0x7fffffff && threadIdx.x == 0) {
+            s_box[0] = a.wander->r0[wid]; s_box[2] = s_box[0] + kWinRows - 1;
+            s_box[1] = a.wander->c0[wid]; s_box[3] = s_box[1] + kWinCols - 1;
+        }
+        const bool placed = wid != 0x7fffffff;
+        __syncthreads();
+        if (!placed && !fits && threadIdx.x == 0) {
+            // a box larger than the window: the first wave's box decides
             s_box[0] = r_lo; s_box[1] = c_lo; s_box[2] = r_hi; s_box[3] = c_hi;
         }
         __syncthreads();
@@ -1836,16 +1876,27 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
         if (threadIdx.x == 0) {
             uint32_t tot = 0;
             for (int q = 0; q < kBlock / 64; ++q) tot += s_surv[q];
-            s_surv[kBlock / 64] = tot ? atomicAdd(&ctl->count[out_slot][xcd], tot) : 0u;
+            s_surv[kBlock / 64] = tot ? atomicAdd(&ctl->count[out_slot][xcd], static_cast<uint32_t>(kBlock)) : 0xFFFFFFFFu;
         }
         __syncthreads();
         basei = s_surv[kBlock / 64];
-        for (int q = 0; q < wv; ++q) basei += s_surv[q];
+        if (basei != 0xFFFFFFFFu) {
+            // the block keeps its kBlock slots (every lane its own): the dead leave tombstones
+            a.list_out[xcd * a.cap + basei + threadIdx.x] = active ? t : -1;
+            if (active) {
+                TrackState o;
+                o.pos = static_cast<int32_t>(row | (col << 16));
+                o.k = k;
+                o.dirs = static_cast<uint32_t>(kKOfRing >> (4 * rc)) & 0xFu;
+                o.aux = s.aux;
+                a.state[t] = o;
+            }
+        }
     } else {
         if (lane == 0 && nsurv) basei = atomicAdd(&ctl->count[out_slot][xcd], static_cast<uint32_t>(nsurv));
         basei = __shfl(basei, 0);
     }
-    if (active) {
+    if (HM != 6 && active) {
         const int rank = __popcll(live & ((1ull << lane) - 1ull));
         a.list_out[xcd * a.cap + basei + rank] = t;
         TrackState o;
@@ -2415,40 +2466,145 @@ __global__ __launch_bounds__(1024) void k_rebalance_lists(const int32_t *__restr
 }
 static_assert(kXcd == 8, "k_rebalance_lists deals with j & 7 / j >> 3");
 
-// Wandering batches (k_step_thr<6>): the live tracks sorted by the 64 x 64 tile they are in, then
-// dealt to the lists round-robin like k_rebalance_lists, so that a block's tracks share a basin.
-// A pseudo-launch: keys of every list slot (dead slots sort to the end), hipcub sort with the list
-// itself as the values, deal of the first `total` sorted ids.
-constexpr uint32_t kWanderDeadKey = 1u << 18;
+// Wandering batches (k_step_thr<6>).  A pseudo-launch between two stepper launches:
+//   k_wander_windows  where are the live tracks?  Histogram on a coarse grid (kWinRows / 4 x
+//                     kWinCols / 4 cells per bin, in LDS), then greedily the densest window of
+//                     4 x 4 bins, kWanderWindows times (each round removes the tracks it covers);
+//                     on the solved 10 m field two windows hold 99.96 % of the survivors
+//   k_wander_keys     key of a list slot = index of the first window that holds its track (tracks
+//                     outside all windows and dead slots sort to the end)
+//   hipcub sort       5 bits, the list itself as the values
+//   k_deal_sorted     each window's run starts at a multiple of kXcd * kBlock tracks and is dealt
+//                     round-robin to the lists, so every block of every list is filled from ONE
+//                     window; the gaps are tombstones (track id -1)
+// k_step_thr<6> keeps the blocks' slots (it reserves kBlock slots per block with a survivor and
+// writes tombstones for its dead), so the sort holds until the host asks for the next one.
+__global__ __launch_bounds__(1024) void k_wander_windows(const int32_t *__restrict__ list_in, const TrackState *__restrict__ state,
+                                                        const TrackCtl *__restrict__ ctl, int in_slot, uint32_t cap,
+                                                        int rows, int cols, WanderWindows *__restrict__ out)
+{
+    __shared__ uint32_t h[kWanderBins];
+    __shared__ unsigned long long s_best;
+    const int nbr = (rows + kBinRows - 1) / kBinRows, nbc = (cols + kBinCols - 1) / kBinCols;
+    const int nb = nbr * nbc;                                        // <= kWanderBins (host)
+    for (int q = threadIdx.x; q < nb; q += 1024) h[q] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < cap * kXcd; i += 1024) {
+        const uint32_t x = i / cap, il = i - x * cap;
+        if (il >= ctl->count[in_slot][x]) continue;
+        const int32_t t = list_in[i];
+        if (t < 0) continue;
+        const int32_t pos = state[t].pos;
+        atomicAdd(&h[((pos & 0xFFFF) / kBinRows) * nbc + ((pos >> 16) & 0xFFFF) / kBinCols], 1u);
+    }
+    __syncthreads();
+    int n = 0;
+    for (; n < kWanderWindows; ++n) {
+        if (threadIdx.x == 0) s_best = 0ull;
+        __syncthreads();
+        unsigned long long best = 0ull;
+        for (int q = threadIdx.x; q < nb; q += 1024) {
+            const int i = q / nbc, j = q - i * nbc;
+            uint32_t sum = 0;
+            for (int di = 0; di < 4 && i + di < nbr; ++di)
+                for (int dj = 0; dj < 4 && j + dj < nbc; ++dj) sum += h[(i + di) * nbc + j + dj];
+            const unsigned long long v = (static_cast<unsigned long long>(sum) << 32) | static_cast<uint32_t>(nb - 1 - q);   // ties: lowest bin
+            best = v > best ? v : best;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_down(best, off);
+            best = o > best ? o : best;
+        }
+        if ((threadIdx.x & 63) == 0) atomicMax(&s_best, best);
+        __syncthreads();
+        const unsigned long long win = s_best;
+        __syncthreads();
+        if ((win >> 32) == 0ull) break;
+        const int q = nb - 1 - static_cast<int>(win & 0xFFFFFFFFull), i = q / nbc, j = q - i * nbc;
+        if (threadIdx.x < 16) {
+            const int di = threadIdx.x >> 2, dj = threadIdx.x & 3;
+            if (i + di < nbr && j + dj < nbc) h[(i + di) * nbc + j + dj] = 0;
+        }
+        if (threadIdx.x == 0) { out->r0[n] = i * kBinRows; out->c0[n] = j * kBinCols; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out->n = n;
+}
+
 __global__ __launch_bounds__(kBlock) void k_wander_keys(const int32_t *__restrict__ list_in, const TrackState *__restrict__ state,
                                                        const TrackCtl *__restrict__ ctl, int in_slot, uint32_t cap,
-                                                       uint32_t *__restrict__ keys)
+                                                       const WanderWindows *__restrict__ win, uint32_t *__restrict__ keys)
 {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= cap * kXcd) return;
     const uint32_t x = i / cap, il = i - x * cap;
-    uint32_t key = kWanderDeadKey;
+    uint32_t key = kWanderWindows + 1;                               // dead slot
     if (il < ctl->count[in_slot][x]) {
-        const int32_t pos = state[list_in[i]].pos;
-        key = ((static_cast<uint32_t>(pos & 0xFFFF) >> 6) << 9) | ((static_cast<uint32_t>(pos >> 16) & 0xFFFFu) >> 6);
+        const int32_t t = list_in[i];
+        if (t >= 0) {
+            const int32_t pos = state[t].pos;
+            key = static_cast<uint32_t>(wander_window_of(win, win->n, pos & 0xFFFF, (pos >> 16) & 0xFFFF));
+            if (key >= static_cast<uint32_t>(win->n)) key = kWanderWindows;   // outside every window
+        }
     }
     keys[i] = key;
 }
 
-__global__ __launch_bounds__(1024) void k_deal_sorted(const int32_t *__restrict__ sorted, int32_t *__restrict__ list_out,
-                                                     TrackCtl *ctl, int in_slot, int out_slot, int zero_slot, uint32_t cap)
+__global__ __launch_bounds__(1024) void k_deal_sorted(const uint32_t *__restrict__ sorted_keys, const int32_t *__restrict__ sorted,
+                                                     int32_t *__restrict__ list_out, TrackCtl *ctl, int out_slot, int zero_slot, uint32_t cap)
 {
-    __shared__ uint32_t s_total;
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (int x = 0; x < kXcd; ++x) { run += ctl->count[in_slot][x]; ctl->count[zero_slot][x] = 0; }
-        s_total = run;
+    // run of key k: [lo[k], lo[k + 1]) in the sorted order, dealt from position off[k] on
+    __shared__ uint32_t lo[kWanderWindows + 3], off[kWanderWindows + 3];
+    const uint32_t slots = cap * kXcd;
+    constexpr uint32_t kRun = kXcd * kBlock;
+    if (threadIdx.x <= kWanderWindows + 2) {
+        // first index whose key is >= threadIdx.x
+        uint32_t a = 0, b = slots;
+        while (a < b) {
+            const uint32_t m = (a + b) / 2;
+            if (sorted_keys[m] < threadIdx.x) a = m + 1; else b = m;
+        }
+        lo[threadIdx.x] = a;
     }
     __syncthreads();
-    const uint32_t total = s_total;
-    for (uint32_t j = blockIdx.x * 1024u + threadIdx.x; j < total; j += gridDim.x * 1024u)
-        list_out[(j & (kXcd - 1)) * cap + (j >> 3)] = sorted[j];
-    if (blockIdx.x == 0 && threadIdx.x < kXcd) ctl->count[out_slot][threadIdx.x] = (total + kXcd - 1 - threadIdx.x) / kXcd;
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int k = 0; k <= kWanderWindows; ++k) {                  // (key kWanderWindows + 1 = dead: not dealt)
+            off[k] = run;
+            run += (lo[k + 1] - lo[k] + kRun - 1) / kRun * kRun;
+        }
+        off[kWanderWindows + 1] = run;
+        if (run > slots) {
+            // no room for the padding (nearly every slot is live): dense deal, blocks may mix windows
+            run = 0;
+            for (int k = 0; k <= kWanderWindows + 1; ++k) { off[k] = run; if (k <= kWanderWindows) run += lo[k + 1] - lo[k]; }
+            off[kWanderWindows + 1] = (run + kRun - 1) / kRun * kRun;
+            off[kWanderWindows + 2] = 1;                             // dense
+        } else {
+            off[kWanderWindows + 2] = 0;
+        }
+    }
+    __syncthreads();
+    const uint32_t total = off[kWanderWindows + 1];                  // a multiple of kRun
+    const bool dense = off[kWanderWindows + 2] != 0;
+    for (uint32_t g = blockIdx.x * 1024u + threadIdx.x; g < total; g += gridDim.x * 1024u) {
+        int32_t t = -1;
+        if (dense) {
+            if (g < lo[kWanderWindows + 1]) t = sorted[g];
+        } else {
+            int k = 0;
+#pragma unroll
+            for (int q = 1; q <= kWanderWindows; ++q) k += off[q] <= g ? 1 : 0;
+            const uint32_t j = lo[k] + (g - off[k]);
+            if (j < lo[k + 1]) t = sorted[j];
+        }
+        list_out[(g & (kXcd - 1)) * cap + (g >> 3)] = t;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < kXcd) {
+        ctl->count[out_slot][threadIdx.x] = total / kXcd;
+        ctl->count[zero_slot][threadIdx.x] = 0;
+    }
 }
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -2463,6 +2619,7 @@ struct Workspace {
     size_t sort_temp_bytes;
     uint32_t *bucket;            // the same visits ordered by raster tile (oblique headings)
     uint32_t *tile_count, *tile_start, *tile_cursor, *item_start;   // [kTilesMax] each, item_start one more
+    WanderWindows *wander;
     uint32_t *visits;            // [kVisitSteps][visit_stride] visited cells of one launch
     long long visit_stride;
     uint32_t cap;                // slots per XCD list
@@ -2522,6 +2679,8 @@ static size_t workspace_layout(int64_t n, char *base, Workspace *ws)
         ws->item_start = ws->tile_cursor + kTilesMax;
     }
     off = align_up(off + sizeof(uint32_t) * (4 * kTilesMax + 1), 256);
+    if (ws) ws->wander = reinterpret_cast<WanderWindows *>(base + off);
+    off = align_up(off + sizeof(WanderWindows), 256);
     return off;
 }
 
@@ -2768,7 +2927,7 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
     {
         PriorArg pa;
         for (int k = 0; k < 9; ++k) pa.v[k] = p->prior[k];
-        hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(64), 0, st, ws.ctl, pa, ws.thr);
+        hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(64), 0, st, ws.ctl, pa, ws.thr, ws.wander);
         SSRS_HIP_CHECK(hipGetLastError());
     }
     const bool coherent = (p->flags & SSRS_TRACKS_NO_SCHEDULE) == 0;
@@ -2823,6 +2982,7 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
     a.coherent = coherent ? 1 : 0;
     a.cap = ws.cap;
     a.thr = ws.thr;
+    a.wander = ws.wander;
     a.vcap = ws.cap;
     const bool lean = p->memory_parameter == 1 && traj == nullptr;
     const bool ring = (p->flags & SSRS_TRACKS_RING_TABLE) != 0;
@@ -2877,12 +3037,16 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
     if (scattered) binning_on = tiles_on = false;
     // threshold stepper, front outgrown the row window (tracks wander): atomics behind the per-lane
     // visit cache instead of tile buckets (A/B switch SSRS_TRACKS_NO_VISIT_CACHE)
-    const bool cache_ok = thr && hist != nullptr && std::getenv("SSRS_TRACKS_BLOCK_WINDOW") != nullptr;
+    // (never while trajectories are recorded: those launches use the visit-buffer kernels, which
+    // know no tombstones)
+    const bool cache_ok = thr && hist != nullptr && !(rec && rec->complete) && std::getenv("SSRS_TRACKS_NO_BLOCK_WINDOW") == nullptr;
     bool cached = cache_ok && scattered;
     bool want_wander_sort = cached;
-    int wander_sorts = 0, wander_cooldown = 0, stable_batches = 0;
+    int wander_sorts = 0, wander_cooldown = 0, stable_batches = 0, upper_from = 0;
     uint32_t prev_total = 0;
-    const bool wander_sort_ok = ntracks >= 8192;          // (the key arrays hold 2 n words >= the list slots)
+    // (the key arrays hold 2 n words >= the list slots; the coarse grid of k_wander_windows fits its LDS)
+    const bool wander_sort_ok = ntracks >= 8192 &&
+                                static_cast<long long>((p->rows + kBinRows - 1) / kBinRows) * ((p->cols + kBinCols - 1) / kBinCols) <= kWanderBins;
     // private histogram copies live behind the regular workspace when the caller gave room
     const size_t ncell = static_cast<size_t>(p->rows) * static_cast<size_t>(p->cols);
     const size_t ws_base = align_up(ssrs_tracks_workspace_bytes(ntracks), 256);
@@ -2941,35 +3105,42 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
     // bound on the longest XCD list
     uint32_t upper = static_cast<uint32_t>(ntracks < static_cast<int64_t>(ws.cap) ? ntracks : ws.cap);
     int batches = 0, checked = 0, judge_from = 0, last_Sl = 0;
-    int window_launches = 0, tile_launches = 0;
+    int window_launches = 0, tile_launches = 0, block_window_launches = 0;
     bool finished = false;
     int rc = SSRS_OK;
     // Termination: every live track either finishes or takes S moves per
     // launch and k < max_moves, so the live count reaches 0.
     while (!finished && rc == SSRS_OK) {
         if (want_wander_sort && cached && wander_sort_ok && launch > 0) {
-            // pseudo-launch: list[launch & 1] -> sorted by tile -> list[(launch + 1) & 1]
+            // pseudo-launch: list[launch & 1] -> windows, keys, sort -> padded deal into list[(launch + 1) & 1]
             const uint32_t slots = ws.cap * kXcd;
             uint32_t *k0 = reinterpret_cast<uint32_t *>(ws.keys[0]), *k1 = reinterpret_cast<uint32_t *>(ws.keys[1]);
             int32_t *sorted = reinterpret_cast<int32_t *>(ws.bucket);
+            hipLaunchKernelGGL(k_wander_windows, dim3(1), dim3(1024), 0, st, ws.list[launch & 1], ws.state, ws.ctl, launch & 3, ws.cap,
+                               p->rows, p->cols, ws.wander);
             hipLaunchKernelGGL(k_wander_keys, dim3((slots + kBlock - 1) / kBlock), dim3(kBlock), 0, st, ws.list[launch & 1], ws.state,
-                               ws.ctl, launch & 3, ws.cap, k0);
+                               ws.ctl, launch & 3, ws.cap, ws.wander, k0);
             size_t temp_bytes = ws.sort_temp_bytes;
             if (hipcub::DeviceRadixSort::SortPairs(ws.sort_temp, temp_bytes, k0, k1, ws.list[launch & 1], sorted,
-                                                   static_cast<int>(slots), 0, 19, st) != hipSuccess) {
+                                                   static_cast<int>(slots), 0, 5, st) != hipSuccess) {
                 rc = set_error(SSRS_ERR_HIP, "wander sort failed");
                 break;
             }
-            hipLaunchKernelGGL(k_deal_sorted, dim3(64), dim3(1024), 0, st, sorted, ws.list[(launch + 1) & 1], ws.ctl,
-                               launch & 3, (launch + 1) & 3, (launch + 2) & 3, ws.cap);
+            hipLaunchKernelGGL(k_deal_sorted, dim3(64), dim3(1024), 0, st, k1, sorted, ws.list[(launch + 1) & 1], ws.ctl,
+                               (launch + 1) & 3, (launch + 2) & 3, ws.cap);
             ++launch;
             ++wander_sorts;
             want_wander_sort = false;
             want_rebalance = false;
             wander_cooldown = 3;
-            rebalance_cooldown = 3;
             marks_adjacent = false;
+            // the padded deal makes the lists LONGER (each window's run is rounded up to whole blocks of
+            // every list): raise the bound now, and let no batch queued before this point lower it
+            const unsigned long long padded = static_cast<unsigned long long>(upper) + (kWanderWindows + 1ull) * kBlock;
+            upper = padded > ws.cap ? ws.cap : static_cast<uint32_t>(padded);
+            upper_from = batches;
         }
+        if (cached) want_rebalance = false;          // (the lists carry tombstones; the wander sort deals evenly)
         if (want_rebalance && launch > 0) {
             // pseudo-launch: list[launch & 1] -> list[(launch + 1) & 1], counts likewise
             hipLaunchKernelGGL(k_rebalance_lists, dim3(1), dim3(1024), 0, st, ws.list[launch & 1], ws.list[(launch + 1) & 1],
@@ -3088,6 +3259,7 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                     }
                     const bool rev = thr_prior.rev_ok != 0 && std::getenv("SSRS_TRACKS_NO_REV") == nullptr;
                     if (cached && !a.visits) {
+                        ++block_window_launches;
                         if (rev) hipLaunchKernelGGL((k_step_thr<6, false, true>), dim3(blocks), dim3(kBlock), 0, st, a, thr_prior);
                         else hipLaunchKernelGGL((k_step_thr<6>), dim3(blocks), dim3(kBlock), 0, st, a, thr_prior);
                         break;
@@ -3196,14 +3368,19 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
             memcpy(tot, &host_counts[kSlotWords * cs + offsetof(TrackCtl, steps) / sizeof(uint32_t)], sizeof(tot));
             ++checked;
             if (c == 0) { finished = true; break; }
-            upper = c;   // the live count only shrinks; a stale bound is safe
+            // the live count only shrinks, a stale bound is safe -- except across a wander sort
+            upper = (checked - 1 >= upper_from || c > upper) ? c : upper;
             uint32_t total = 0;
             for (int x = 0; x < kXcd; ++x) total += cnt[x];
             if (tiles_on && cache_ok && !force_tiles && a.pf_dir != 0) {
                 // a front that outgrew the row window goes through tile buckets while part of the batch
                 // still travels; once nobody finishes any more (the survivors roam their basins until
                 // max_moves) the block windows take over
-                if (prev_total != 0 && total >= prev_total - prev_total / 32 && ++stable_batches >= 2) {
+                // (nobody finishing YET is not stable: some must have finished, or the batch is older
+                // than two raster crossings)
+                const bool started = static_cast<long long>(total) * 50 < static_cast<long long>(ntracks) * 49 ||
+                                     it_done > 2ll * (p->rows + p->cols);
+                if (started && prev_total != 0 && total >= prev_total - prev_total / 32 && ++stable_batches >= 2) {
                     tiles_on = false;
                     cached = true;
                     want_wander_sort = true;
@@ -3256,7 +3433,7 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                     fprintf(stderr, "[tracks] batch %d block windows: %llu steps, %llu strays (%.3f), live %u\n", checked, dsteps, dstray,
                             dsteps ? static_cast<double>(dstray) / static_cast<double>(dsteps) : 0.0, total);
                 if (wander_cooldown > 0) --wander_cooldown;
-                else if (dsteps > 0 && dstray * 8 > dsteps && wander_sorts < 12) want_wander_sort = true;
+                else if (dsteps > 0 && dstray * 64 > dsteps && wander_sorts < 12) want_wander_sort = true;
             }
             // batches that never binned (small, unsorted, very wide rasters) give no stray
             // signal: tracks still alive after four raster crossings are wandering
@@ -3291,6 +3468,8 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
         stats->launches = launch;
         stats->window_launches = window_launches;
         stats->tile_launches = tile_launches;
+        stats->block_window_launches = block_window_launches;
+        stats->wander_sorts = wander_sorts;
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, ev_first, ev_last) == hipSuccess) stats->wall_ms = ms;
         if (profile) {

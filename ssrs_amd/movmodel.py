@@ -328,7 +328,9 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
                       dict(total_steps=int(stats.total_steps), launches=int(stats.launches),
                            kernel_ms=float(stats.kernel_ms), wall_ms=float(stats.wall_ms),
                            hist_ms=float(stats.hist_ms), window_launches=int(stats.window_launches),
-                           tile_launches=int(stats.tile_launches), recorded=bool(recorded)))
+                           tile_launches=int(stats.tile_launches),
+                           block_window_launches=int(stats.block_window_launches),
+                           wander_sorts=int(stats.wander_sorts), recorded=bool(recorded)))
 
 
 def generate_simulated_tracks(move_dirn, start_location, grid_shape, memory_parameter=1,

@@ -828,3 +828,46 @@ def test_one_band_batch_is_redealt_over_the_lists(gpu):
         del os.environ['SSRS_TRACKS_NO_REBALANCE'], os.environ['SSRS_TRACKS_FIXED_STEPS']
     assert torch.equal(plain.hist, got.hist) and torch.equal(plain.lengths, got.lengths)
     assert plain.stats['launches'] > got.stats['launches'], 'the re-deal / grown launches did not happen'
+
+
+def test_block_windows_for_batches_that_roam_basins(gpu):
+    """Wells in the potential trap a good part of a 20k batch until max_moves: the threshold stepper
+    leaves the row window, goes through tile buckets while the rest of the batch still travels, then
+    sorts the survivors into histogram windows (k_wander_windows / k_deal_sorted) and counts them in
+    LDS (k_step_thr<6>: tombstoned lists, reversal rows in the fast path).  Lengths, end cells and
+    histogram are the oracle's; SSRS_TRACKS_NO_BLOCK_WINDOW / SSRS_TRACKS_NO_REV are the A/B switches."""
+    import os
+    from ssrs_amd import movmodel
+    from oracle import c_oracle
+    rows, cols = 700, 1100
+    upd, pot = _random_field_case(rows, cols, 5)
+    pot = pot.copy()
+    rr, cc = np.arange(rows)[:, None], np.arange(cols)[None, :]
+    for r0, c0, w in ((200, 300, 14.), (330, 820, 18.), (340, 330, 10.), (520, 600, 16.)):
+        pot -= (700. * np.exp(-((rr - r0) ** 2 + (cc - c0) ** 2) / (2. * w ** 2))).astype(np.float32)
+    rng = np.random.default_rng(77)
+    n = 20000
+    starts = np.stack([rng.integers(2, 12, n), rng.integers(5, cols - 5, n)], 1)
+    cap = 9000
+    ref = c_oracle.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=4, max_moves=cap, want_traj=False)
+    assert (ref['lengths'] - 1 >= cap).mean() > 0.05           # enough of them are trapped
+    os.environ['SSRS_TRACKS_FIXED_STEPS'] = '1'               # launches stay 128 steps deep: enough batches to get there
+    got = movmodel.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=4, use_table=True, thr=True,
+                                   max_moves=cap, steps_per_launch=128)
+    assert got.stats['block_window_launches'] > 0 and got.stats['wander_sorts'] > 0, got.stats
+    assert np.array_equal(got.lengths.cpu().numpy(), ref['lengths'])
+    assert np.array_equal(got.ends.cpu().numpy(), ref['ends'])
+    assert np.array_equal(got.hist.cpu().numpy().view(np.uint32), ref['hist'])
+    for switch in ('SSRS_TRACKS_NO_BLOCK_WINDOW', 'SSRS_TRACKS_NO_REV'):
+        os.environ[switch] = '1'
+        try:
+            other = movmodel.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=4, use_table=True, thr=True,
+                                             max_moves=cap, steps_per_launch=128)
+        finally:
+            del os.environ[switch]
+        assert torch.equal(other.hist, got.hist) and torch.equal(other.lengths, got.lengths), switch
+    del os.environ['SSRS_TRACKS_FIXED_STEPS']
+    assert other.stats['block_window_launches'] > 0            # (the last switch only changes the kernel variant)
+    grown = movmodel.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=4, use_table=True, thr=True,
+                                     max_moves=cap, steps_per_launch=128)
+    assert torch.equal(grown.hist, got.hist) and torch.equal(grown.lengths, got.lengths)
