@@ -236,7 +236,11 @@ int ssrs_transition_thr_build(const double *updraft, const float *potential, con
 
 /* Bytes of device scratch ssrs_tracks_simulate needs for `ntracks` (about 8.3 KB per
  * track: two buffers of 1024 steps x 4 B for the launch's visited cells, in slot and in
- * raster-tile order; a launch takes as many steps as they hold for the live tracks). */
+ * raster-tile order; a launch takes as many steps as they hold for the live tracks).
+ * With the threshold table, a batch whose survivors roam a few basins of the potential
+ * field until max_moves (the solved 10 m field: 44 %) is sorted into up to 16 histogram
+ * windows of 144 x 256 cells and counted in LDS (SsrsTrackStats.block_window_launches);
+ * nothing to size for it. */
 size_t ssrs_tracks_workspace_bytes(int64_t ntracks);
 /* The same plus room for `hist_copies` (2..64) private copies of the histogram.  A
  * workspace of this size lets ssrs_tracks_simulate privatise the histogram once a batch
