@@ -229,7 +229,8 @@ int ssrs_transition_ring_build(const double *updraft, const float *potential, fl
  * poisoned rows and rows where the unmasked prior decides are flag entries (T1 = 0xFFFF > T2 = code).
  * Eight planes (one per last move) of 4-byte entries at a power-of-two stride,
  * ssrs_transition_thr_bytes(rows, cols) bytes in all, 64-byte aligned; the table belongs to one
- * heading (`prior` [host], 9 doubles = SsrsTrackParams.prior).  rows * cols <= 2^27. */
+ * heading (`prior` [host], 9 doubles = SsrsTrackParams.prior).  rows * cols <= 2^26; the
+ * table carries a guard band of (cols + 2) dwords at either end. */
 size_t ssrs_transition_thr_bytes(int rows, int cols);
 int ssrs_transition_thr_build(const double *updraft, const float *potential, const double *prior,
                               float *thr, int rows, int cols, void *stream);

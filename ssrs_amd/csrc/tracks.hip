@@ -667,6 +667,7 @@ struct StepArgs {
     uint32_t cap;                // slots per XCD list (multiple of kBlock); list x = [x*cap, (x+1)*cap)
     long long it_base;           // k_step_thr: global iteration of this launch's first step
     int plane_shift;             // k_step_thr: log2 of the byte stride between the table's eight planes
+    uint32_t guard;              // k_step_thr: bytes of guard band before plane 0 (table points at the band)
     int v16_offset;              // k_step_thr<4>: plan offset (rows + cols): first start row = ctl->par_min - v16_offset
     int pf_dir, pf_rc;           // k_step_thr prefetch wave: row direction of the front (+1 north, -1 south),
                                  // ring position of the heading
@@ -1573,11 +1574,35 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
     const uint32_t xcd = blockIdx.x % kXcd;
     const uint32_t nlive = ctl->count[in_slot][xcd];
     __shared__ int s_it;                                  // PF: iteration reached by the stepping waves
+    // Candidate table: row rc = the three admissible moves after last move rc in the order of the
+    // decision (a: u < T1, b: u < T2, c: else) as {cell delta a, b, c, packed (nc | dr << 3 | dc << 5)
+    // of a, b, c, plane offset a, b, c, -}.  A lane reads its row when its last move is known, long
+    // before the gather returns; what then depends on the gather is two subtractions, two compares and
+    // the selects of the delta and of the plane.  Plane offsets include the guard band and the byte
+    // offset is a SUM (plane + 4 cell, modulo 2^32): a speculative neighbour of a boundary cell lies
+    // below plane 0 or beyond plane 7, inside the bands.
+    __shared__ alignas(16) uint32_t s_lut[8 * 8];
+    if (threadIdx.x < 8) {
+        const uint32_t r8 = threadIdx.x;
+        const uint32_t ord8 = static_cast<uint32_t>(kRingOrder >> (6u * r8)) & 63u;
+        uint32_t pack = 0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const uint32_t ncj = (r8 + 7u + ((ord8 >> (2 * j)) & 3u)) & 7u;
+            const uint32_t drj = (kRingDr >> (2u * ncj)) & 3u, dcj = (kRingDc >> (2u * ncj)) & 3u;
+            s_lut[r8 * 8 + j] = drj * static_cast<uint32_t>(a.cols) + dcj - (static_cast<uint32_t>(a.cols) + 1u);
+            s_lut[r8 * 8 + 4 + j] = a.guard + (ncj << a.plane_shift);
+            pack |= (ncj | (drj << 3) | (dcj << 5)) << (8 * j);
+        }
+        s_lut[r8 * 8 + 3] = pack;
+        s_lut[r8 * 8 + 7] = 0;
+    }
+    if (!PF) __syncthreads();
     if (PF) {
         if (threadIdx.x == 0) s_it = -1;
         __syncthreads();
         if (threadIdx.x >= kBlock) {
-            const PfArgs pa = {a.list_in, a.state, a.table, a.ctl, a.it_base, a.cap, a.coherent, a.steps,
+            const PfArgs pa = {a.list_in, a.state, reinterpret_cast<const char *>(a.table) + a.guard, a.ctl, a.it_base, a.cap, a.coherent, a.steps,
                                a.pf_dir, a.pf_rc, a.rows, a.cols, a.plane_shift};
             thr_prefetch_wave(pa, xcd, nlive, &s_it);
             return;
@@ -1679,7 +1704,17 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
     }
     wave_burn = __builtin_amdgcn_readfirstlane(wave_burn);
     const uint32_t psh = static_cast<uint32_t>(a.plane_shift);
-    uint32_t e = *reinterpret_cast<const uint32_t *>(tab + ((rc << psh) | (cell << 2)));
+    uint32_t plane = a.guard + (rc << psh);
+    uint32_t e = *reinterpret_cast<const uint32_t *>(tab + (plane + (cell << 2)));
+    uint4 lutA = *reinterpret_cast<const uint4 *>(&s_lut[rc * 8]), lutB = *reinterpret_cast<const uint4 *>(&s_lut[rc * 8 + 4]);
+    // REV: the row of the move along the heading, wave-uniform
+    uint32_t rvA[4] = {0, 0, 0, 0}, rvB[3] = {0, 0, 0};
+    if (REV) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rvA[j] = __builtin_amdgcn_readfirstlane(s_lut[pr.rev_rc * 8 + j]);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) rvB[j] = __builtin_amdgcn_readfirstlane(s_lut[pr.rev_rc * 8 + 4 + j]);
+    }
     // column of the cell, kept up to date only while the burn-in phase of the loop runs
     uint32_t colv = static_cast<uint32_t>(s.pos >> 16) & 0xFFFFu;
     const uint32_t zone_lo = 2u * ucols, zone_hi = (urows - 2u) * ucols, zone_col = ucols - 2u;
@@ -1705,14 +1740,28 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
             w0 = pend_a; w1 = pend_b;
         }
         const uint32_t ufi = w0 >> 16;                               // top 16 bits of u
-        uint32_t eu = e, rcd = rc;
+        uint32_t eu = e;
+        uint32_t la = lutA.x, lb = lutA.y, lc = lutA.z, lpk = lutA.w, pa = lutB.x, pb = lutB.y, pc = lutB.z;
         if (REV && !burn) {
             const bool rev = e == kThrReversal;
             eu = rev ? pr.rev_e : e;
-            rcd = rev ? pr.rev_rc : rc;
+            la = rev ? rvA[0] : la; lb = rev ? rvA[1] : lb; lc = rev ? rvA[2] : lc; lpk = rev ? rvA[3] : lpk;
+            pa = rev ? rvB[0] : pa; pb = rev ? rvB[1] : pb; pc = rev ? rvB[2] : pc;
         }
         const int32_t d1 = static_cast<int32_t>(ufi) - static_cast<int32_t>(eu & 0xFFFFu);
         const int32_t d2 = static_cast<int32_t>(ufi) - static_cast<int32_t>(eu >> 16);
+        // ---- the next gather, issued before anything else is known: a (u < T1), b (u < T2) or c; a lane
+        // that does not step now stays.  Flag entries and near-ties take one of the three as well (a
+        // neighbour cell: inside the table or its guard bands) and are put right below.
+        const bool s1 = d1 < 0, s2 = d2 < 0;
+        uint32_t dl = s2 ? lb : lc, pl = s2 ? pb : pc;
+        dl = s1 ? la : dl;  pl = s1 ? pa : pl;
+        dl = stm ? dl : 0u; pl = stm ? pl : plane;
+        uint32_t cell_n = cell + dl;
+        uint32_t e_n = *reinterpret_cast<const uint32_t *>(tab + (pl + (cell_n << 2)));
+        // ---- which one it was (off the chain)
+        const uint32_t fld = (lpk >> (s1 ? 0u : (s2 ? 8u : 16u))) & 0xFFu;
+        uint32_t nc = fld & 7u, dr = (fld >> 3) & 3u, dc = (fld >> 5) & 3u;
         // ufi - T in {-1, 0}: the uniform is within rounding of a boundary; T1 > T2 (d1 < d2): a flag entry
         bool special = (static_cast<uint32_t>(d1 + 1) < 2u) | (static_cast<uint32_t>(d2 + 1) < 2u) | (d1 < d2);
         if (burn) {
@@ -1720,9 +1769,6 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
             special = special | (zone & (it <= it_burn));
         }
         special = special & (stm != 0u);
-        const uint32_t ord = static_cast<uint32_t>(kRingOrder >> __umul24(6u, rcd)) & 63u;
-        const uint32_t neg = (static_cast<uint32_t>(d1) >> 31) + (static_cast<uint32_t>(d2) >> 31);     // 2 - sel
-        uint32_t nc = (rcd + 7u + ((ord >> (4u - 2u * neg)) & 3u)) & 7u;
         uint32_t base = cell, base_col = colv;
         const uint32_t cell_before = cell;
         uint32_t go = stm;
@@ -1770,11 +1816,21 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
                     if (HM == 6) { wr += er - static_cast<int>(r); wc += ec - static_cast<int>(c); }      // the nudge
                 }
             }
+            // the move as decided (every lane: the others find what they already have) and the gather again
+            dr = (kRingDr >> (2u * nc)) & 3u;
+            dc = (kRingDc >> (2u * nc)) & 3u;
+            const uint32_t moved_to = base + __umul24(dr, ucols) + dc - back;
+            const uint32_t cell_t = (moved_to & go) | (cell & ~go);
+            const uint32_t pl_t = ((a.guard + (nc << psh)) & go) | (plane & ~go);
+            // (only the lanes that guessed wrong: the first gather stays one load for both paths, issued
+            // before this branch)
+            if ((cell_t != cell_n) | (pl_t != pl)) e_n = *reinterpret_cast<const uint32_t *>(tab + (pl_t + (cell_t << 2)));
+            cell_n = cell_t;
+            pl = pl_t;
         }
-        // ---- move, selected with the mask (no branch: idle lanes keep cell, rc, k)
-        const uint32_t dr = (kRingDr >> (2u * nc)) & 3u, dc = (kRingDc >> (2u * nc)) & 3u;
-        const uint32_t moved_to = base + __umul24(dr, ucols) + dc - back;
-        cell = (moved_to & go) | (cell & ~go);
+        // ---- commit (idle lanes keep cell, rc, k)
+        cell = cell_n;
+        plane = pl;
         rc = (nc & go) | (rc & ~go);
         k -= static_cast<int>(go);                                    // go is 0 or -1
         if (burn) {
@@ -1782,7 +1838,9 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
             const uint32_t moved_col = base == cell_before ? colv + dc - 1u : base_col + dc - 1u;
             colv = (moved_col & go) | (colv & ~go);
         }
-        e = *reinterpret_cast<const uint32_t *>(tab + ((rc << psh) | (cell << 2)));
+        e = e_n;
+        lutA = *reinterpret_cast<const uint4 *>(&s_lut[rc * 8]);
+        lutB = *reinterpret_cast<const uint4 *>(&s_lut[rc * 8 + 4]);
         // ---- presence histogram (see k_step_tracks)
         if (HM == 1) {
             *vrow = cell | ~go;                                       // idle: 0xFFFFFFFF
@@ -2828,10 +2886,17 @@ extern "C" int ssrs_transition_ring_build(const double *updraft, const float *po
     return SSRS_OK;
 }
 
+// The stepper issues the next gather BEFORE it knows whether the lane's entry was a flag (boundary
+// cell, ...): such a lane's speculative address is a neighbour of its cell, up to cols + 1 cells
+// outside a plane.  A guard band at both ends of the allocation keeps those loads inside it (their
+// values are never used).
+static size_t thr_guard_bytes(int cols) { return align_up((static_cast<size_t>(cols) + 2) * 4, 256); }
+
 extern "C" size_t ssrs_transition_thr_bytes(int rows, int cols)
 {
     if (rows <= 0 || cols <= 0) return 0;
-    return static_cast<size_t>(8) << thr_plane_shift(rows, cols);     // eight planes of rows * cols dwords
+    // eight planes of rows * cols dwords, a power-of-two stride apart, between two guard bands
+    return (static_cast<size_t>(8) << thr_plane_shift(rows, cols)) + 2 * thr_guard_bytes(cols);
 }
 
 extern "C" int ssrs_transition_thr_build(const double *updraft, const float *potential,
@@ -2839,19 +2904,20 @@ extern "C" int ssrs_transition_thr_build(const double *updraft, const float *pot
 {
     SSRS_REQUIRE(updraft && thr && prior, "ssrs_transition_thr_build: updraft/prior/thr is NULL");
     SSRS_REQUIRE(rows >= 3 && cols >= 3, "ssrs_transition_thr_build: need rows, cols >= 3");
-    SSRS_REQUIRE(static_cast<size_t>(rows) * static_cast<size_t>(cols) <= (1ull << 27),
-                 "ssrs_transition_thr_build: the table is addressed with 32-bit offsets (rows * cols <= 2^27)");
+    SSRS_REQUIRE(static_cast<size_t>(rows) * static_cast<size_t>(cols) <= (1ull << 26),
+                 "ssrs_transition_thr_build: the table and its guard bands are addressed with 32-bit offsets (rows * cols <= 2^26)");
     SSRS_REQUIRE((reinterpret_cast<uintptr_t>(thr) & 63u) == 0,
                  "ssrs_transition_thr_build: table must be 64-byte aligned");
     ThrPrior pr;
     prior_tables(prior, &pr);
     const int tx = (cols + kTabW - 1) / kTabW, ty = (rows + kTabH - 1) / kTabH, nt = tx * ty;
+    uint32_t *planes = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(thr) + thr_guard_bytes(cols));
     if (potential)
         hipLaunchKernelGGL(k_transition_thr<true>, dim3(static_cast<unsigned>(nt)), dim3(kBlock), 0, as_stream(stream),
-                           updraft, potential, reinterpret_cast<uint32_t *>(thr), rows, cols, tx, nt, pr, thr_plane_shift(rows, cols));
+                           updraft, potential, planes, rows, cols, tx, nt, pr, thr_plane_shift(rows, cols));
     else
         hipLaunchKernelGGL(k_transition_thr<false>, dim3(static_cast<unsigned>(nt)), dim3(kBlock), 0, as_stream(stream),
-                           updraft, potential, reinterpret_cast<uint32_t *>(thr), rows, cols, tx, nt, pr, thr_plane_shift(rows, cols));
+                           updraft, potential, planes, rows, cols, tx, nt, pr, thr_plane_shift(rows, cols));
     SSRS_HIP_CHECK(hipGetLastError());
     return SSRS_OK;
 }
@@ -2992,10 +3058,11 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
         SSRS_REQUIRE(!ring && table && updraft && lean && a.fast && (S & 1) == 0,
                      "ssrs_tracks_simulate: SSRS_TRACKS_THR_TABLE needs table + updraft, memory_parameter 1, "
                      "scaling_parameter 1, no direct trajectory output, no EXACT_ONLY and an even steps_per_launch");
-        SSRS_REQUIRE(static_cast<size_t>(p->rows) * static_cast<size_t>(p->cols) <= (1ull << 27),
-                     "ssrs_tracks_simulate: the threshold table needs rows * cols <= 2^27");
+        SSRS_REQUIRE(static_cast<size_t>(p->rows) * static_cast<size_t>(p->cols) <= (1ull << 26),
+                     "ssrs_tracks_simulate: the threshold table needs rows * cols <= 2^26");
         prior_tables(p->prior, &thr_prior);
         a.plane_shift = thr_plane_shift(p->rows, p->cols);
+        a.guard = static_cast<uint32_t>(thr_guard_bytes(p->cols));
         // prefetch wave: the heading's ring position (0 = north, 4 = south); A/B switch SSRS_TRACKS_NO_PREFETCH
         a.pf_dir = (coherent && std::getenv("SSRS_TRACKS_NO_PREFETCH") == nullptr)
                        ? (geom.cos_t > 0.98 ? 1 : (geom.cos_t < -0.98 ? -1 : 0)) : 0;

@@ -95,7 +95,7 @@ def make_track_params(grid_shape, move_dirn, memory_parameter=1, scaling_paramet
     return p
 
 
-THR_MAX_CELLS = 1 << 27        # the threshold table is addressed with 32-bit offsets
+THR_MAX_CELLS = 1 << 26        # the threshold table is addressed with 32-bit offsets
 
 
 def table_kind(table):
