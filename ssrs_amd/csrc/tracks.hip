@@ -1707,14 +1707,7 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
     uint32_t plane = a.guard + (rc << psh);
     uint32_t e = *reinterpret_cast<const uint32_t *>(tab + (plane + (cell << 2)));
     uint4 lutA = *reinterpret_cast<const uint4 *>(&s_lut[rc * 8]), lutB = *reinterpret_cast<const uint4 *>(&s_lut[rc * 8 + 4]);
-    // REV: the row of the move along the heading, wave-uniform
-    uint32_t rvA[4] = {0, 0, 0, 0}, rvB[3] = {0, 0, 0};
-    if (REV) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) rvA[j] = __builtin_amdgcn_readfirstlane(s_lut[pr.rev_rc * 8 + j]);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) rvB[j] = __builtin_amdgcn_readfirstlane(s_lut[pr.rev_rc * 8 + 4 + j]);
-    }
+    const uint32_t rev_e = pr.rev_e, rev_rc = pr.rev_rc;
     // column of the cell, kept up to date only while the burn-in phase of the loop runs
     uint32_t colv = static_cast<uint32_t>(s.pos >> 16) & 0xFFFFu;
     const uint32_t zone_lo = 2u * ucols, zone_hi = (urows - 2u) * ucols, zone_col = ucols - 2u;
@@ -1728,7 +1721,7 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
         hbase = a.hist_copies + static_cast<size_t>((i >> 6) % static_cast<uint32_t>(a.ncopies)) * static_cast<size_t>(ncell);
     int it = 0;
 
-    auto one_step = [&](const bool even, const bool burn) {
+    auto one_step = [&](const bool even, const bool burn) __attribute__((always_inline)) {
         if (PF && even && (it & 7) == 0 && (threadIdx.x & 63) == 0) atomicMax(&s_it, it);
         // st: all ones when this lane steps now
         const uint32_t stm = (static_cast<uint32_t>(it - rel) < span) ? 0xFFFFFFFFu : 0u;
@@ -1740,28 +1733,44 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
             w0 = pend_a; w1 = pend_b;
         }
         const uint32_t ufi = w0 >> 16;                               // top 16 bits of u
-        uint32_t eu = e;
-        uint32_t la = lutA.x, lb = lutA.y, lc = lutA.z, lpk = lutA.w, pa = lutB.x, pb = lutB.y, pc = lutB.z;
-        if (REV && !burn) {
+        // Two decodes.  LUT: the candidates of the last move come from the LDS table and the next gather
+        // is issued before anything else is known -- shortest dependent chain, for launches that wait
+        // on their gathers (fronts: misses, a dozen lines per gather).  ARITH (the REV variants outside
+        // the burn-in): the candidates are worked out from the ring position after the entry is known,
+        // one gather after the special test -- fewer instructions, for wandering batches whose gathers
+        // hit in L1 / L2 and whose lone waves are bound by what they issue (measured on the solved field:
+        // 3.23 s per pass against 3.50 s with the LUT decode and its reversal merge).
+        const bool arith = REV && !burn;
+        int32_t d1, d2;
+        uint32_t nc, dr = 0u, dc = 0u, cell_n = cell, pl = plane, e_n = e;
+        if (!arith) {
+            const uint32_t la = lutA.x, lb = lutA.y, lc = lutA.z, lpk = lutA.w, pa = lutB.x, pb = lutB.y, pc = lutB.z;
+            d1 = static_cast<int32_t>(ufi) - static_cast<int32_t>(e & 0xFFFFu);
+            d2 = static_cast<int32_t>(ufi) - static_cast<int32_t>(e >> 16);
+            // a (u < T1), b (u < T2) or c; a lane that does not step now stays.  Flag entries and near-ties
+            // take one of the three as well (a neighbour cell: inside the table or its guard bands) and
+            // are put right below.
+            const bool s1 = d1 < 0, s2 = d2 < 0;
+            const uint32_t pcur = plane;
+            uint32_t dl = s2 ? lb : lc;
+            pl = s2 ? pb : pc;
+            dl = s1 ? la : dl;  pl = s1 ? pa : pl;
+            dl = stm ? dl : 0u; pl = stm ? pl : pcur;
+            cell_n = cell + dl;
+            e_n = *reinterpret_cast<const uint32_t *>(tab + (pl + (cell_n << 2)));
+            // which one it was (off the chain)
+            const uint32_t fld = (lpk >> (s1 ? 0u : (s2 ? 8u : 16u))) & 0xFFu;
+            nc = fld & 7u; dr = (fld >> 3) & 3u; dc = (fld >> 5) & 3u;
+        } else {
+            // a reversal row is an ordinary row of the move along the heading with the prior's thresholds
             const bool rev = e == kThrReversal;
-            eu = rev ? pr.rev_e : e;
-            la = rev ? rvA[0] : la; lb = rev ? rvA[1] : lb; lc = rev ? rvA[2] : lc; lpk = rev ? rvA[3] : lpk;
-            pa = rev ? rvB[0] : pa; pb = rev ? rvB[1] : pb; pc = rev ? rvB[2] : pc;
+            const uint32_t eu = rev ? rev_e : e, rcd = rev ? rev_rc : rc;
+            d1 = static_cast<int32_t>(ufi) - static_cast<int32_t>(eu & 0xFFFFu);
+            d2 = static_cast<int32_t>(ufi) - static_cast<int32_t>(eu >> 16);
+            const uint32_t ord = static_cast<uint32_t>(kRingOrder >> __umul24(6u, rcd)) & 63u;
+            const uint32_t neg = (static_cast<uint32_t>(d1) >> 31) + (static_cast<uint32_t>(d2) >> 31);     // 2 - sel
+            nc = (rcd + 7u + ((ord >> (4u - 2u * neg)) & 3u)) & 7u;
         }
-        const int32_t d1 = static_cast<int32_t>(ufi) - static_cast<int32_t>(eu & 0xFFFFu);
-        const int32_t d2 = static_cast<int32_t>(ufi) - static_cast<int32_t>(eu >> 16);
-        // ---- the next gather, issued before anything else is known: a (u < T1), b (u < T2) or c; a lane
-        // that does not step now stays.  Flag entries and near-ties take one of the three as well (a
-        // neighbour cell: inside the table or its guard bands) and are put right below.
-        const bool s1 = d1 < 0, s2 = d2 < 0;
-        uint32_t dl = s2 ? lb : lc, pl = s2 ? pb : pc;
-        dl = s1 ? la : dl;  pl = s1 ? pa : pl;
-        dl = stm ? dl : 0u; pl = stm ? pl : plane;
-        uint32_t cell_n = cell + dl;
-        uint32_t e_n = *reinterpret_cast<const uint32_t *>(tab + (pl + (cell_n << 2)));
-        // ---- which one it was (off the chain)
-        const uint32_t fld = (lpk >> (s1 ? 0u : (s2 ? 8u : 16u))) & 0xFFu;
-        uint32_t nc = fld & 7u, dr = (fld >> 3) & 3u, dc = (fld >> 5) & 3u;
         // ufi - T in {-1, 0}: the uniform is within rounding of a boundary; T1 > T2 (d1 < d2): a flag entry
         bool special = (static_cast<uint32_t>(d1 + 1) < 2u) | (static_cast<uint32_t>(d2 + 1) < 2u) | (d1 < d2);
         if (burn) {
@@ -1816,17 +1825,27 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
                     if (HM == 6) { wr += er - static_cast<int>(r); wc += ec - static_cast<int>(c); }      // the nudge
                 }
             }
-            // the move as decided (every lane: the others find what they already have) and the gather again
+            if (!arith) {
+                // the move as decided (every lane: the others find what they already have) and the gather
+                // again for the lanes that guessed wrong (the first gather stays ONE load for both paths,
+                // issued before this branch)
+                dr = (kRingDr >> (2u * nc)) & 3u;
+                dc = (kRingDc >> (2u * nc)) & 3u;
+                const uint32_t moved_to = base + __umul24(dr, ucols) + dc - back;
+                const uint32_t cell_t = (moved_to & go) | (cell & ~go);
+                const uint32_t pl_t = ((a.guard + (nc << psh)) & go) | (plane & ~go);
+                if ((cell_t != cell_n) | (pl_t != pl)) e_n = *reinterpret_cast<const uint32_t *>(tab + (pl_t + (cell_t << 2)));
+                cell_n = cell_t;
+                pl = pl_t;
+            }
+        }
+        if (arith) {
             dr = (kRingDr >> (2u * nc)) & 3u;
             dc = (kRingDc >> (2u * nc)) & 3u;
             const uint32_t moved_to = base + __umul24(dr, ucols) + dc - back;
-            const uint32_t cell_t = (moved_to & go) | (cell & ~go);
-            const uint32_t pl_t = ((a.guard + (nc << psh)) & go) | (plane & ~go);
-            // (only the lanes that guessed wrong: the first gather stays one load for both paths, issued
-            // before this branch)
-            if ((cell_t != cell_n) | (pl_t != pl)) e_n = *reinterpret_cast<const uint32_t *>(tab + (pl_t + (cell_t << 2)));
-            cell_n = cell_t;
-            pl = pl_t;
+            cell_n = (moved_to & go) | (cell & ~go);
+            pl = a.guard + (((nc & go) | (rc & ~go)) << psh);
+            e_n = *reinterpret_cast<const uint32_t *>(tab + (pl + (cell_n << 2)));
         }
         // ---- commit (idle lanes keep cell, rc, k)
         cell = cell_n;
@@ -1839,8 +1858,10 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
             colv = (moved_col & go) | (colv & ~go);
         }
         e = e_n;
-        lutA = *reinterpret_cast<const uint4 *>(&s_lut[rc * 8]);
-        lutB = *reinterpret_cast<const uint4 *>(&s_lut[rc * 8 + 4]);
+        if (!arith) {
+            lutA = *reinterpret_cast<const uint4 *>(&s_lut[rc * 8]);
+            lutB = *reinterpret_cast<const uint4 *>(&s_lut[rc * 8 + 4]);
+        }
         // ---- presence histogram (see k_step_tracks)
         if (HM == 1) {
             *vrow = cell | ~go;                                       // idle: 0xFFFFFFFF
