@@ -871,3 +871,39 @@ def test_block_windows_for_batches_that_roam_basins(gpu):
     grown = movmodel.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=4, use_table=True, thr=True,
                                      max_moves=cap, steps_per_launch=128)
     assert torch.equal(grown.hist, got.hist) and torch.equal(grown.lengths, got.lengths)
+
+
+def test_block_windows_when_nearly_every_track_is_trapped(gpu):
+    """8192 tracks (the lists have no spare slots), a wide trough that catches most of them: the
+    padded deal of the wander sort does not fit and falls back to the dense one (blocks may then mix
+    windows; their strays are global atomics), and a batch flagged SCATTERED starts in block windows
+    before any sort.  Results are the oracle's either way."""
+    import os
+    from ssrs_amd import movmodel
+    from oracle import c_oracle
+    rows, cols = 300, 2200
+    upd, pot = _random_field_case(rows, cols, 9)
+    pot = pot.copy()
+    rr, cc = np.arange(rows)[:, None], np.arange(cols)[None, :]
+    for c0 in (300, 1100, 1900):                               # three pits side by side
+        pot -= (900. * np.exp(-((rr - 120) ** 2 / (2. * 12. ** 2) + (cc - c0) ** 2 / (2. * 260. ** 2)))).astype(np.float32)
+    rng = np.random.default_rng(3)
+    n = 8192
+    starts = np.stack([rng.integers(2, 10, n), rng.integers(5, cols - 5, n)], 1)
+    cap = 5000
+    ref = c_oracle.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=6, max_moves=cap, want_traj=False)
+    assert (ref['lengths'] - 1 >= cap).mean() > 0.5
+    os.environ['SSRS_TRACKS_FIXED_STEPS'] = '1'
+    try:
+        got = movmodel.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=6, use_table=True, thr=True,
+                                       max_moves=cap, steps_per_launch=64)
+        sc = movmodel.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=6, use_table=True, thr=True,
+                                      max_moves=cap, steps_per_launch=64, scattered=True)
+    finally:
+        del os.environ['SSRS_TRACKS_FIXED_STEPS']
+    assert got.stats['block_window_launches'] > 0 and got.stats['wander_sorts'] > 0, got.stats
+    assert sc.stats['block_window_launches'] > 0, sc.stats
+    for res in (got, sc):
+        assert np.array_equal(res.lengths.cpu().numpy(), ref['lengths'])
+        assert np.array_equal(res.ends.cpu().numpy(), ref['ends'])
+        assert np.array_equal(res.hist.cpu().numpy().view(np.uint32), ref['hist'])
