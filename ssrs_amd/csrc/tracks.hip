@@ -558,7 +558,8 @@ struct alignas(16) TrackCtl {
     uint32_t par_min;            // smallest along-track start coordinate (schedule)
     unsigned long long steps;    // total moves taken
     unsigned long long strays;   // visits the binning kernel could not place in its LDS window
-    unsigned long long pad;
+    uint32_t bin_done;           // blocks of the running k_bin_visits16 that have finished (read-back by the last)
+    uint32_t pad;
     double prior[9];             // directional prior of this call (read by the slow paths)
     double pad2;
 };
@@ -956,7 +957,7 @@ __global__ void k_ctl_init(TrackCtl *ctl, const PriorArg pr, double *__restrict_
     const int d = threadIdx.x;
     if (d == 33) wander->n = 0;
     if (d < 32) reinterpret_cast<uint32_t *>(ctl->count)[d] = 0;
-    if (d == 32) { ctl->error = 0; ctl->par_min = 0xFFFFFFFFu; ctl->steps = 0; ctl->strays = 0; ctl->pad = 0; ctl->pad2 = 0.0; }
+    if (d == 32) { ctl->error = 0; ctl->par_min = 0xFFFFFFFFu; ctl->steps = 0; ctl->strays = 0; ctl->bin_done = 0; ctl->pad = 0; ctl->pad2 = 0.0; }
     if (d < 9) ctl->prior[d] = pr.v[d];
     if (d >= 9) return;
     const double *prior = pr.v;
@@ -2111,7 +2112,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_visits(const uint32_t *__re
 __global__ __launch_bounds__(kBinThreads) void k_bin_visits16(const uint16_t *__restrict__ visits, long long stride, int steps,
                                                              TrackCtl *__restrict__ ctl, int slot,
                                                              uint32_t *__restrict__ hist, int rows, int cols, uint32_t cap,
-                                                             int v16_offset, long long it_base)
+                                                             int v16_offset, long long it_base, uint32_t *host_out, int host_words)
 {
     __shared__ uint32_t bins[kBinCells];
     uint32_t nslots[kXcd];
@@ -2153,7 +2154,13 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_visits16(const uint16_t *__
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) stray += __shfl_down(stray, off);
-    if ((threadIdx.x & 63) == 0 && stray) atomicAdd(&ctl->strays, static_cast<unsigned long long>(stray));
+    if ((threadIdx.x & 63) == 0 && stray) {
+        // (with a read-back the count must have landed before this block reports itself done: take the
+        // atomic's return value, i.e. wait for THIS one -- a fence at the end would also wait for the
+        // flush below to drain, 70 -> 175 us per launch)
+        const unsigned long long before = atomicAdd(&ctl->strays, static_cast<unsigned long long>(stray));
+        if (host_out && before == 0xFFFFFFFFFFFFFFFFull) hist[0] += 0u;      // keeps the returning form
+    }
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < kBinCells; k += kBinThreads * 4) {
         uint32_t n[4];
@@ -2165,6 +2172,25 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_visits16(const uint16_t *__
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             if (n[q]) atomicAdd(&hist[base + k + q * kBinThreads], n[q]);     // n > 0: a visited cell, inside the raster
+    }
+    // The batch's read-back (live counts, steps, strays: the head of the control block), written to the
+    // host's pinned slot by the last block of the batch's last binning kernel: a copy on the stream
+    // would cost it a blit kernel and two more dependency gaps (~16 us per launch, profiles/r02_notes.md)
+    if (host_out) {
+        __shared__ bool s_last;
+        __syncthreads();
+        if (threadIdx.x == 0) s_last = atomicAdd(&ctl->bin_done, 1u) == gridDim.x - 1u;
+        __syncthreads();
+        if (s_last) {
+            // (no system-scope fence: it would write the whole L2 back, ~100 us; the slot is fine-grained
+            // host memory, stored to directly, and the host reads it after the stream's event)
+            if (static_cast<int>(threadIdx.x) < host_words)
+                __hip_atomic_store(host_out + threadIdx.x,
+                                   __hip_atomic_load(reinterpret_cast<const uint32_t *>(ctl) + threadIdx.x, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (threadIdx.x == 0) ctl->bin_done = 0u;
+        }
     }
 }
 
@@ -3164,6 +3190,7 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
     constexpr int kSlotWords = 40;           // 160 bytes of TrackCtl: counts .. strays
     static_assert(offsetof(TrackCtl, strays) + sizeof(unsigned long long) <= kSlotWords * sizeof(uint32_t), "read-back slot");
     int slot_row[kRing] = {};
+    const bool direct_read_back = std::getenv("SSRS_TRACKS_COPY_READ_BACK") == nullptr;      // A/B switch
     // (profile mode: every batch gets its own event, which is also the start mark of the next launch)
     hipEvent_t ev_batch[kRing] = {};
     if (!profile)
@@ -3241,6 +3268,8 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
         // one launch per batch while launches are long and few (the host then sees the batch die one
         // launch earlier: one empty launch at the end of a short run instead of two); two otherwise
         const int depth = (thr && last_Sl >= 512 && launch < 24) ? 1 : kBatch;
+        const int slot = batches % kRing;
+        bool read_back_done = false;             // the batch's last binning kernel wrote the slot itself
         for (int j = 0; j < depth; ++j, ++launch) {
             a.launch = launch;
             a.list_in = (launch == 0 && !coherent) ? nullptr : ws.list[launch & 1];
@@ -3380,16 +3409,20 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
             if (profile) mark(1);      // end of the stepper launch
             if (bin_window) {
                 ++window_launches;
-                if (v16)
+                if (v16) {
+                    uint32_t *out = (j == depth - 1 && direct_read_back) ? &host_counts[kSlotWords * slot] : nullptr;
                     hipLaunchKernelGGL(k_bin_visits16, dim3((Sl + 1) / 2), dim3(kBinThreads), 0, st, reinterpret_cast<const uint16_t *>(a.visits),
-                                       a.visit_stride, Sl, ws.ctl, launch & 3, hist, p->rows, p->cols, a.vcap, a.v16_offset, a.it_base);
+                                       a.visit_stride, Sl, ws.ctl, launch & 3, hist, p->rows, p->cols, a.vcap, a.v16_offset, a.it_base,
+                                       out, kSlotWords);
+                    read_back_done = out != nullptr;
+                }
                 else if (hist_t)
                     hipLaunchKernelGGL(k_bin_visits, dim3(Sl), dim3(kBinThreads), 0, st, a.visits, a.visit_stride,
                                        ws.ctl, launch & 3, hist_t, p->cols, p->rows, a.vcap);
                 else
                     hipLaunchKernelGGL(k_bin_visits, dim3(Sl), dim3(kBinThreads), 0, st, a.visits, a.visit_stride,
                                        ws.ctl, launch & 3, hist, p->rows, p->cols, a.vcap);
-                if (profile) mark(2);
+                if (profile && !read_back_done) mark(2);      // (else the batch's event below is this mark)
             }
             if (bin_tiles) {
                 ++tile_launches;
@@ -3425,14 +3458,13 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
         }
         if (rc != SSRS_OK) break;
         // survivors of this batch = input count of the next launch
-        const int slot = batches % kRing;
         // ring slot = the head of the control block in one copy: [4][8] list counts, error, par_min,
         // steps (2 words), strays (2 words); the row this batch's survivors went to is count[launch & 3]
-        bool queued = hipMemcpyAsync(&host_counts[kSlotWords * slot], ws.ctl, kSlotWords * sizeof(uint32_t),
-                                     hipMemcpyDeviceToHost, st) == hipSuccess;
+        bool queued = read_back_done || hipMemcpyAsync(&host_counts[kSlotWords * slot], ws.ctl, kSlotWords * sizeof(uint32_t),
+                                                       hipMemcpyDeviceToHost, st) == hipSuccess;
         if (queued && profile) {
             const size_t before = ev_marks.size();
-            mark(0);
+            mark(read_back_done ? 2 : 0);
             queued = ev_marks.size() > before;
             if (queued) ev_batch[slot] = ev_marks.back();
         } else if (queued) {
