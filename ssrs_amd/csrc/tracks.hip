@@ -1738,9 +1738,8 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
         // is issued before anything else is known -- shortest dependent chain, for launches that wait
         // on their gathers (fronts: misses, a dozen lines per gather).  ARITH (the REV variants outside
         // the burn-in): the candidates are worked out from the ring position after the entry is known,
-        // one gather after the special test -- fewer instructions, for wandering batches whose gathers
-        // hit in L1 / L2 and whose lone waves are bound by what they issue (measured on the solved field:
-        // 3.23 s per pass against 3.50 s with the LUT decode and its reversal merge).
+        // one gather after the special test -- measured on the solved field: 3.23 s per pass against
+        // 3.50 s with the LUT decode and its reversal merge on the chain.
         const bool arith = REV && !burn;
         int32_t d1, d2;
         uint32_t nc, dr = 0u, dc = 0u, cell_n = cell, pl = plane, e_n = e;
