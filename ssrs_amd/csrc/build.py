@@ -61,7 +61,10 @@ def build_probe(defines, tag):
 
 
 if __name__ == '__main__':
-    if '--probe-k2a' in sys.argv:     # table-builder timing probes: tools/dev/time_k2a.py ONLY (the tables are garbage)
+    if '--probe-k3' in sys.argv:      # binning-kernel timing probes (wrong histograms: bench timing only, no checks)
+        for tag, defs in (('k3_noflush', ['SSRS_PROBE_K3_NOFLUSH']), ('k3_noread', ['SSRS_PROBE_K3_NOREAD'])):
+            print(build_probe(defs, tag))
+    elif '--probe-k2a' in sys.argv:     # table-builder timing probes: tools/dev/time_k2a.py ONLY (the tables are garbage)
         for tag, defs in (('k2a_nostore', ['SSRS_PROBE_K2A_NOSTORE']), ('k2a_noload', ['SSRS_PROBE_K2A_NOLOAD']), ('k2a_pad', ['SSRS_PROBE_K2A_PAD=4352']), ('k2a_pad2', ['SSRS_PROBE_K2A_PAD=1048576+4352'])):
             print(build_probe(defs, tag))
     elif '--probe' in sys.argv:

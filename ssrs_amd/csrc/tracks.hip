@@ -2135,7 +2135,11 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_visits16(const uint16_t *__
 #pragma unroll
                 for (int q = 0; q < kU; ++q) {
                     const uint32_t jj = j + q * kBinThreads;
+#ifdef SSRS_PROBE_K3_NOREAD
+                    c[q] = jj < npair ? (jj * 2654435761u) % 24000u * 65537u : 0xFFFFFFFFu;
+#else
                     c[q] = jj < npair ? v2[jj] : 0xFFFFFFFFu;
+#endif
                 }
 #pragma unroll
                 for (int q = 0; q < kU; ++q) {
@@ -2170,7 +2174,12 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_visits16(const uint16_t *__
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            if (n[q]) atomicAdd(&hist[base + k + q * kBinThreads], n[q]);     // n > 0: a visited cell, inside the raster
+#ifdef SSRS_PROBE_K3_NOFLUSH
+            if (n[q] == 0x12345678u)
+#else
+            if (n[q])
+#endif
+                atomicAdd(&hist[base + k + q * kBinThreads], n[q]);           // n > 0: a visited cell, inside the raster
     }
     // The batch's read-back (live counts, steps, strays: the head of the control block), written to the
     // host's pinned slot by the last block of the batch's last binning kernel: a copy on the stream
