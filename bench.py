@@ -187,7 +187,9 @@ def solved_leg(args, movmodel, layers, dem, starts_h, gridsize, res, seed):
         'launches': o.stats['launches'], 'window_launches': o.stats['window_launches'],
         'tile_launches': o.stats['tile_launches'], 'block_window_launches': o.stats['block_window_launches'],
         'solver': {'iterations': sst['iterations'], 'residual': sst['residual'], 'converged': sst['converged'],
-                   'seconds': t_solve, 'rel_tol': 1e-15, 'amg_levels': sst['amg_levels']},
+                   'seconds': t_solve, 'rel_tol': 1e-15, 'amg_levels': sst['amg_levels'],
+                   'setup_ms': sst.get('setup_ms'), 'workspace_used_gb': round(sst.get('workspace_used', 0) / 1e9, 2),
+                   'workspace_reserved_gb': round(sst.get('workspace_bytes', 0) / 1e9, 2)},
         'what': 'first tracks of the same start list through ssrs_potential_solve\'s field (library default '
                 'tolerance), one pass, table build included; not part of `value`',
     }
