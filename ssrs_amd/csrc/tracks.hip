@@ -4,8 +4,8 @@
 //   ssrs/movmodel.py:185-202  get_track_restrictions      -> restriction()
 //   ssrs/movmodel.py:205-217  move_away_from_boundary     -> nudge in step loop
 //   ssrs/movmodel.py:220-244  generate_move_probabilities -> choose_move()
-//   ssrs/movmodel.py:264-318  generate_simulated_tracks   -> k_step_lean, k_step_tracks
-//   ssrs/movmodel.py:410-419  compute_presence_counts     -> k_bin_visits, k_bin_bucket / uint32 atomics
+//   ssrs/movmodel.py:264-318  generate_simulated_tracks   -> k_step_thr, k_step_lean, k_step_tracks
+//   ssrs/movmodel.py:410-419  compute_presence_counts     -> k_bin_visits[16], k_bin_bucket, k_step_thr<6> / uint32 atomics
 //   numpy mtrand `choice`     cumsum, /last, searchsorted 'right'
 //
 // Structure (MI355X-first, not a port of the per-track python loop):
@@ -17,13 +17,17 @@
 //   * the per-step uniform is counter-based (rocRAND Philox4x32-10 engine),
 //     a pure function of (seed, global track id, step): any sharding of tracks
 //     over launches / GPUs gives bit-identical trajectories.
-//   * three data paths: 3x3 window gathers of the f64 updraft + f32 potential
+//   * four data paths: 3x3 window gathers of the f64 updraft + f32 potential
 //     rasters (reference-shaped, k_step_tracks<MODE_FLUIDFLOW / MODE_UPDRAFT>); a
 //     precomputed per-cell table of 8 f64 weights (any movement model,
-//     k_step_tracks<MODE_TABLE>); and, for the reference's default model (direction
-//     memory 1, nu = 1), the f32 ring table read with ONE 12-byte gather per step by
-//     the flat kernel k_step_lean, whose guarded decision hands near-ties to the
-//     exact sequence (three tiers, see choose_three_ring_f32).
+//     k_step_tracks<MODE_TABLE>); for the reference's default model (direction
+//     memory 1, nu = 1) the THRESHOLD table -- per cell and last move the two 16-bit
+//     decision thresholds, ONE 4-byte gather per step, k_transition_thr + k_step_thr
+//     (the default; candidate table in LDS and early gather for fronts, reversal rows
+//     in the fast path and a histogram window per block in LDS for batches that roam
+//     basins, k_wander_windows / k_deal_sorted) -- and round 1's f32 ring table
+//     (k_step_lean, one 12-byte gather, three-tier guarded decision).  Every fast
+//     decision hands its near-ties to the exact sequence.
 //   * tracks live in one list per XCD (column bands stay in one L2); the histogram is
 //     a visit buffer + LDS binning kernel while the batch moves as a front (a row /
 //     column window per step for axis-aligned headings, k_bin_visits; tile buckets per
