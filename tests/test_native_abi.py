@@ -32,6 +32,26 @@ def test_version_and_error_text():
     assert isinstance(lib.ssrs_last_error(), bytes)
 
 
+def test_threshold_table_size_includes_its_guard_bands():
+    """Eight planes at a power-of-two stride between two guard bands of (cols + 2) entries, rounded up to
+    256 bytes (the stepper's speculative gathers of boundary cells land there); a table too large for
+    32-bit offsets is refused by the builder."""
+    from ssrs_amd import _native
+    lib = _native.lib()
+    lib.ssrs_transition_thr_bytes.restype = C.c_size_t
+    for rows, cols in ((5000, 6000), (96, 128), (5, 5)):
+        stride = 256
+        while stride < rows * cols * 4:
+            stride *= 2
+        guard = -(-(cols + 2) * 4 // 256) * 256
+        assert lib.ssrs_transition_thr_bytes(rows, cols) == 8 * stride + 2 * guard
+    assert lib.ssrs_transition_thr_bytes(0, 10) == 0
+    dummy = (C.c_double * 9)()
+    buf = (C.c_char * 64)()
+    rc = lib.ssrs_transition_thr_build(buf, None, dummy, buf, 9000, 9000, None)      # 8.1e7 cells > 2^26
+    assert rc == _native.SSRS_ERR_INVALID and b'2^26' in lib.ssrs_last_error()
+
+
 def test_argument_validation_needs_no_gpu():
     from ssrs_amd import _native
     lib = _native.lib()
