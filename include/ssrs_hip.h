@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SSRS_VERSION 102 /* 0.1.2 */
+#define SSRS_VERSION 103 /* 0.1.3 */
 
 #define SSRS_OK 0
 #define SSRS_ERR_INVALID (-1) /* bad argument (message says which) */
@@ -192,6 +192,9 @@ typedef struct SsrsTrackStats {
     int32_t block_window_launches; /* ... in the stepper, into a histogram window per block in LDS
                                 (threshold table; batches whose survivors roam a few basins) */
     int32_t wander_sorts;    /* times the live tracks were sorted into such windows */
+    int32_t timed_launches;  /* stepper launches whose durations make up kernel_ms (PROFILE) */
+    float first_move_ms;     /* of which: the one-iteration launch of the generic kernel that makes every
+                                track's first move before the threshold stepper takes over (PROFILE; else 0) */
 } SsrsTrackStats;
 
 /* Fills rows/cols/burnin/max_moves/memory/nu and zeroes the rest; `prior` must

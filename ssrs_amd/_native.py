@@ -51,7 +51,8 @@ class SsrsTrackStats(C.Structure):
     _fields_ = [('total_steps', C.c_int64), ('launches', C.c_int32),
                 ('kernel_ms', C.c_float), ('wall_ms', C.c_float), ('hist_ms', C.c_float),
                 ('window_launches', C.c_int32), ('tile_launches', C.c_int32),
-                ('block_window_launches', C.c_int32), ('wander_sorts', C.c_int32)]
+                ('block_window_launches', C.c_int32), ('wander_sorts', C.c_int32),
+                ('timed_launches', C.c_int32), ('first_move_ms', C.c_float)]
 
 
 class SsrsSolveStats(C.Structure):

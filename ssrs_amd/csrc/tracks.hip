@@ -3617,10 +3617,18 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
         if (hipEventElapsedTime(&ms, ev_first, ev_last) == hipSuccess) stats->wall_ms = ms;
         if (profile) {
             float sum = 0.f, hsum = 0.f;
+            int timed = 0;
             for (size_t i = 1; i < ev_marks.size(); ++i) {
                 if (mark_kind[i] == 0 || hipEventElapsedTime(&ms, ev_marks[i - 1], ev_marks[i]) != hipSuccess) continue;
-                if (mark_kind[i] == 1) sum += ms; else hsum += ms;
+                if (mark_kind[i] == 1) {
+                    sum += ms;
+                    if (timed == 0 && thr) stats->first_move_ms = ms;      // (launch 0 of a threshold-table call)
+                    ++timed;
+                } else {
+                    hsum += ms;
+                }
             }
+            stats->timed_launches = timed;
             stats->kernel_ms = sum;
             stats->hist_ms = hsum;
         }

@@ -330,7 +330,8 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
                            hist_ms=float(stats.hist_ms), window_launches=int(stats.window_launches),
                            tile_launches=int(stats.tile_launches),
                            block_window_launches=int(stats.block_window_launches),
-                           wander_sorts=int(stats.wander_sorts), recorded=bool(recorded)))
+                           wander_sorts=int(stats.wander_sorts), timed_launches=int(stats.timed_launches),
+                           first_move_ms=float(stats.first_move_ms), recorded=bool(recorded)))
 
 
 def generate_simulated_tracks(move_dirn, start_location, grid_shape, memory_parameter=1,
