@@ -3173,7 +3173,7 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
     bool scattered = (p->flags & SSRS_TRACKS_SCATTERED) != 0;
     if (scattered) binning_on = tiles_on = false;
     // threshold stepper, front outgrown the row window (tracks wander): atomics behind the per-lane
-    // visit cache instead of tile buckets (A/B switch SSRS_TRACKS_NO_VISIT_CACHE)
+    // block windows in LDS instead of tile buckets (A/B switch SSRS_TRACKS_NO_BLOCK_WINDOW)
     // (never while trajectories are recorded: those launches use the visit-buffer kernels, which
     // know no tombstones)
     const bool cache_ok = thr && hist != nullptr && !(rec && rec->complete) && std::getenv("SSRS_TRACKS_NO_BLOCK_WINDOW") == nullptr;
