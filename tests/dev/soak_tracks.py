@@ -65,6 +65,19 @@ while time.time() - t0 < budget:
                 np.array_equal(res.hist.cpu().numpy().view(np.uint32), ref['hist'])):
             print('TRAJECTORY MISMATCH', dict(seed=seed, rows=rows, cols=cols, n=n, dirn=dirn, kind=kind, spl=spl, mem=mem), kw, flush=True)
             sys.exit(1)
+    if kind == 'wells' and n >= 9000 and mem == 1:
+        # many short launches: the batch gets to the wander sort and the block windows (k_step_thr<6>)
+        os.environ['SSRS_TRACKS_FIXED_STEPS'] = '1'
+        try:
+            res = movmodel.simulate_tracks(dirn, starts, (rows, cols), mem, 1., upd, pot, seed=s, steps_per_launch=32, use_table=True, thr=True)
+        finally:
+            del os.environ['SSRS_TRACKS_FIXED_STEPS']
+        if not (np.array_equal(res.lengths.cpu().numpy(), ref['lengths']) and np.array_equal(res.ends.cpu().numpy(), ref['ends']) and
+                np.array_equal(res.hist.cpu().numpy().view(np.uint32), ref['hist'])):
+            print('MISMATCH (short launches)', dict(seed=seed, rows=rows, cols=cols, n=n, dirn=dirn, kind=kind, mem=mem), res.stats, flush=True)
+            sys.exit(1)
+        n_windowed = globals().get('n_windowed', 0) + (1 if res.stats['block_window_launches'] else 0)
+        globals()['n_windowed'] = n_windowed
     for kw in variants:
         res = movmodel.simulate_tracks(dirn, starts, (rows, cols), mem, 1., upd, pot, seed=s, steps_per_launch=spl, **kw)
         ok = (np.array_equal(res.lengths.cpu().numpy(), ref['lengths']) and
@@ -76,4 +89,4 @@ while time.time() - t0 < budget:
     n_case += 1; n_steps += int(ref['steps'])
     if n_case % 20 == 0:
         print(f'{n_case} cases, {n_steps:.3e} oracle steps, {time.time() - t0:.0f} s', flush=True)
-print(f'soak ok: {n_case} cases x 3-11 GPU variants, {n_steps:.3e} steps each', flush=True)
+print(f'soak ok: {n_case} cases x 3-11 GPU variants, {n_steps:.3e} steps each; {globals().get("n_windowed", 0)} short-launch wells cases reached the block windows', flush=True)
