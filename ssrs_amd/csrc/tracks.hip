@@ -1891,9 +1891,9 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
             const uint32_t key = static_cast<uint32_t>(static_cast<int32_t>(cell) - vbase);
             const bool stray = (go != 0u) & (key >= 0xFFFFu);
             if (__builtin_expect(__any(stray), 0)) {
-                if (stray) atomicAdd(&a.hist[cell], 1u);
-                const unsigned long long sm = __ballot(stray);
-                if ((threadIdx.x & 63) == 0) atomicAdd(&ctl->strays, static_cast<unsigned long long>(__popcll(sm)));
+                // (counted per lane and reported once when the launch ends: one atomic on ctl->strays per
+                // wave-step -- 1.6 M on one address in a launch over a solved field -- took 20-38 ms)
+                if (stray) { atomicAdd(&a.hist[cell], 1u); ++win_stray; }
             }
             *vrow16 = static_cast<uint16_t>((go != 0u && !stray) ? key : 0xFFFFu);
             vrow16 += a.visit_stride;
@@ -1941,6 +1941,8 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
             // (cells of the window outside the raster were never counted)
             if (n) atomicAdd(&a.hist[static_cast<uint32_t>(win_r0 + q / kWinCols) * ucols + static_cast<uint32_t>(win_c0 + q % kWinCols)], n);
         }
+    }
+    if (HM == 6 || HM == 4) {
         unsigned long long ws = win_stray;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) ws += __shfl_down(ws, off);
