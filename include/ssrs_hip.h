@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SSRS_VERSION 103 /* 0.1.3 */
+#define SSRS_VERSION 104 /* 0.1.4 */
 
 #define SSRS_OK 0
 #define SSRS_ERR_INVALID (-1) /* bad argument (message says which) */
@@ -50,6 +50,9 @@ extern "C" {
 #define SSRS_F64 1
 
 int ssrs_version(void);
+/* bit 0: a timing-probe build of the library (a kernel stage is stubbed out on purpose, results are
+ * wrong): product code, tests and bench.py refuse to run against it */
+int ssrs_build_flags(void);
 const char *ssrs_last_error(void);
 /* name[] receives the device name; returns SSRS_OK or SSRS_ERR_HIP */
 int ssrs_device_info(int device, char *name, size_t name_len, int *compute_units,
@@ -233,7 +236,9 @@ int ssrs_transition_ring_build(const double *updraft, const float *potential, fl
  * Eight planes (one per last move) of 4-byte entries at a power-of-two stride,
  * ssrs_transition_thr_bytes(rows, cols) bytes in all, 64-byte aligned; the table belongs to one
  * heading (`prior` [host], 9 doubles = SsrsTrackParams.prior).  rows * cols <= 2^26; the
- * table carries a guard band of (cols + 2) dwords at either end. */
+ * table carries a guard band of (cols + 2) dwords at either end, and the first bytes of the leading band
+ * name the table (magic, rows, cols, the nine prior values): ssrs_tracks_simulate checks them on the device
+ * and returns SSRS_ERR_INVALID for a buffer that is not the threshold table of its raster and prior. */
 size_t ssrs_transition_thr_bytes(int rows, int cols);
 int ssrs_transition_thr_build(const double *updraft, const float *potential, const double *prior,
                               float *thr, int rows, int cols, void *stream);

@@ -23,7 +23,7 @@ SSRS_TRACKS_THR_TABLE = 128
 SSRS_SOLVE_NO_AMG = 1
 
 EXPORTS = (
-    'ssrs_version', 'ssrs_last_error', 'ssrs_device_info', 'ssrs_slope_aspect',
+    'ssrs_version', 'ssrs_build_flags', 'ssrs_last_error', 'ssrs_device_info', 'ssrs_slope_aspect',
     'ssrs_orographic_updraft', 'ssrs_threshold_updraft', 'ssrs_updraft_from_dem',
     'ssrs_lattice_workspace_bytes', 'ssrs_updraft_from_dem_lattice',
     'ssrs_wind_from_lattice', 'ssrs_thermal_seeds', 'ssrs_blur_workspace_bytes',
@@ -81,6 +81,9 @@ def lib():
                 '(hipcc, gfx950). ssrs_amd has no CPU fallback.')
         L = C.CDLL(LIB_PATH)
         L.ssrs_version.restype = C.c_int
+        if L.ssrs_build_flags() & 1 and not os.environ.get('SSRS_ALLOW_PROBE_LIB'):
+            raise ImportError(f'{LIB_PATH} is a timing-probe build (results are wrong on purpose); '
+                              'set SSRS_ALLOW_PROBE_LIB=1 for timing runs only')
         L.ssrs_last_error.restype = C.c_char_p
         L.ssrs_tracks_workspace_bytes.restype = C.c_size_t
         L.ssrs_tracks_workspace_bytes.argtypes = [C.c_int64]

@@ -953,15 +953,36 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
 // "count of thr <= u" IS np.random.choice's pick.
 struct PriorArg { double v[9]; };
 
+// In-band identity of a threshold table: the first bytes of its leading guard band (the speculative
+// gathers that land there never use what they read).  ssrs_tracks_simulate refuses a table whose
+// header does not name this raster and this prior: the f32 / dword table kinds are flat buffers,
+// and a table of another heading has the same layout.
+constexpr unsigned long long kThrMagic = 0x3152485453525353ull;      // "SSRSTHR1"
+struct ThrHeader {
+    unsigned long long magic;
+    int32_t rows, cols;
+    double prior[9];
+};
+static_assert(sizeof(ThrHeader) <= 256, "the header lives in the leading guard band (>= 256 bytes)");
+
 // Start of a call, one kernel instead of two memsets, a copy and a threshold kernel (each of
 // those cost the stream ~6 us): clears the control block, stores the prior, par_min = max, and
 // the prior-fallback thresholds from the by-value prior.
-__global__ void k_ctl_init(TrackCtl *ctl, const PriorArg pr, double *__restrict__ thr, WanderWindows *wander)
+__global__ void k_ctl_init(TrackCtl *ctl, const PriorArg pr, double *__restrict__ thr, WanderWindows *wander,
+                           const ThrHeader *__restrict__ header, int rows, int cols)
 {
     const int d = threadIdx.x;
     if (d == 33) wander->n = 0;
     if (d < 32) reinterpret_cast<uint32_t *>(ctl->count)[d] = 0;
-    if (d == 32) { ctl->error = 0; ctl->par_min = 0xFFFFFFFFu; ctl->steps = 0; ctl->strays = 0; ctl->bin_done = 0; ctl->pad = 0; ctl->pad2 = 0.0; }
+    if (d == 32) {
+        // error bit 1: the threshold table was not built for this raster and this prior
+        uint32_t bad = 0;
+        if (header) {
+            bad = (header->magic != kThrMagic || header->rows != rows || header->cols != cols) ? 2u : 0u;
+            for (int k = 0; k < 9; ++k) bad |= (header->prior[k] != pr.v[k]) ? 2u : 0u;
+        }
+        ctl->error = bad; ctl->par_min = 0xFFFFFFFFu; ctl->steps = 0; ctl->strays = 0; ctl->bin_done = 0; ctl->pad = 0; ctl->pad2 = 0.0;
+    }
     if (d < 9) ctl->prior[d] = pr.v[d];
     if (d >= 9) return;
     const double *prior = pr.v;
@@ -1371,10 +1392,15 @@ struct ThrPrior {
 template <bool HASPOT>
 __global__ __launch_bounds__(kBlock) void k_transition_thr(
     const double *__restrict__ updraft, const float *__restrict__ potential,
-    uint32_t *__restrict__ table_out, int rows, int cols, int tiles_x, int ntiles, const ThrPrior pr, int plane_shift)
+    uint32_t *__restrict__ table_out, int rows, int cols, int tiles_x, int ntiles, const ThrPrior pr, int plane_shift,
+    ThrHeader *__restrict__ header, const PriorArg heading)
 {
     constexpr int LW = kTabW + 2, LH = kTabH + 2;
     __shared__ float2 s_cell[LW * LH];                       // x: 2^-24 / clipped updraft, y: potential
+    if (blockIdx.x == 0 && threadIdx.x < 9) {
+        header->prior[threadIdx.x] = heading.v[threadIdx.x];
+        if (threadIdx.x == 0) { header->magic = kThrMagic; header->rows = rows; header->cols = cols; }
+    }
     const int t = xcd_band(blockIdx.x, ntiles);
     const int r0 = (t / tiles_x) * kTabH, c0 = (t % tiles_x) * kTabW;
     for (int i = threadIdx.x; i < LW * LH; i += kBlock) {
@@ -2136,6 +2162,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_visits16(const uint16_t *__
     for (int x = 0; x < kXcd; ++x) nslots[x] = (ctl->count[slot][x] + 63u) & ~63u;
     const int it0 = 2 * static_cast<int>(blockIdx.x);
     const long long base = (static_cast<long long>(ctl->par_min) - v16_offset + it_base + it0 - 1) * cols;
+    const long long ncell = static_cast<long long>(rows) * cols;
     for (int k = threadIdx.x; k < kBinCells; k += kBinThreads) bins[k] = 0;
     __syncthreads();
     uint32_t stray = 0;
@@ -2166,7 +2193,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_visits16(const uint16_t *__
                         if (key == 0xFFFFu) continue;      // idle slot (or counted by the stepper)
                         key += shift;
                         if (key < kBinCells) atomicAdd(&bins[key], 1u);
-                        else { atomicAdd(&hist[base + key], 1u); ++stray; }     // in the raster: a visited cell
+                        else if (base + key >= 0 && base + key < ncell) { atomicAdd(&hist[base + key], 1u); ++stray; }   // a visited cell
                     }
                 }
             }
@@ -2891,6 +2918,19 @@ static void prior_tables(const double *prior, ThrPrior *out)
     }
 }
 
+// bit 0: a timing-probe build (csrc/build.py --probe*: some SSRS_PROBE_* switch is defined and the
+// results are wrong on purpose).  ssrs_amd refuses to load such a library unless told to.
+extern "C" int ssrs_build_flags(void)
+{
+#if defined(SSRS_PROBE_NO_PHILOX) || defined(SSRS_PROBE_NO_GATHER) || defined(SSRS_PROBE_K2A_NOLOAD) || \
+    defined(SSRS_PROBE_K2A_NOSTORE) || defined(SSRS_PROBE_K2A_PAD) || defined(SSRS_K2A_NT) || \
+    defined(SSRS_PROBE_K3_NOREAD) || defined(SSRS_PROBE_K3_NOFLUSH)
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 extern "C" int ssrs_track_params_init(SsrsTrackParams *p, int rows, int cols,
                                       int memory_parameter, double scaling_parameter)
 {
@@ -2984,12 +3024,15 @@ extern "C" int ssrs_transition_thr_build(const double *updraft, const float *pot
     prior_tables(prior, &pr);
     const int tx = (cols + kTabW - 1) / kTabW, ty = (rows + kTabH - 1) / kTabH, nt = tx * ty;
     uint32_t *planes = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(thr) + thr_guard_bytes(cols));
+    ThrHeader *header = reinterpret_cast<ThrHeader *>(thr);
+    PriorArg heading;
+    for (int k = 0; k < 9; ++k) heading.v[k] = prior[k];
     if (potential)
         hipLaunchKernelGGL(k_transition_thr<true>, dim3(static_cast<unsigned>(nt)), dim3(kBlock), 0, as_stream(stream),
-                           updraft, potential, planes, rows, cols, tx, nt, pr, thr_plane_shift(rows, cols));
+                           updraft, potential, planes, rows, cols, tx, nt, pr, thr_plane_shift(rows, cols), header, heading);
     else
         hipLaunchKernelGGL(k_transition_thr<false>, dim3(static_cast<unsigned>(nt)), dim3(kBlock), 0, as_stream(stream),
-                           updraft, potential, planes, rows, cols, tx, nt, pr, thr_plane_shift(rows, cols));
+                           updraft, potential, planes, rows, cols, tx, nt, pr, thr_plane_shift(rows, cols), header, heading);
     SSRS_HIP_CHECK(hipGetLastError());
     return SSRS_OK;
 }
@@ -3065,7 +3108,9 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
     {
         PriorArg pa;
         for (int k = 0; k < 9; ++k) pa.v[k] = p->prior[k];
-        hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(64), 0, st, ws.ctl, pa, ws.thr, ws.wander);
+        // (a threshold table names its raster and prior in its leading guard band: checked on the device)
+        const ThrHeader *header = (p->flags & SSRS_TRACKS_THR_TABLE) ? reinterpret_cast<const ThrHeader *>(table) : nullptr;
+        hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(64), 0, st, ws.ctl, pa, ws.thr, ws.wander, header, p->rows, p->cols);
         SSRS_HIP_CHECK(hipGetLastError());
     }
     const bool coherent = (p->flags & SSRS_TRACKS_NO_SCHEDULE) == 0;
@@ -3387,7 +3432,9 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
             }
             if (profile && !marks_adjacent) mark(0);
             // 16-bit visit keys: north-bound front through the row window, nothing recorded
-            const bool v16 = thr && bin_window && a.visits == ws.visits && a.pf_dir == 1 && !hist_t && v16_ok;
+            // (the stepper forms the key base (first start row + iteration - 1) * cols in 32 bits)
+            const bool v16 = thr && bin_window && a.visits == ws.visits && a.pf_dir == 1 && !hist_t && v16_ok &&
+                             (it_done + Sl + 2ll * geom.offset) * p->cols < (1ll << 31);
             switch (first_move ? mode0 : mode) {
             case MODE_TABLE:
                 if (thr) {
@@ -3641,6 +3688,10 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
     (void)hipEventDestroy(ev_first);
     (void)hipEventDestroy(ev_last);
     if (rc != SSRS_OK) return rc;
+    if (host_ctl.error & 2u)
+        return set_error(SSRS_ERR_INVALID, "ssrs_tracks_simulate: `table` is not a threshold table built by "
+                         "ssrs_transition_thr_build for this %d x %d raster and params->prior (results discarded)",
+                         p->rows, p->cols);
     if (host_ctl.error)
         return set_error(SSRS_ERR_START, "ssrs_tracks_simulate: a start cell lies outside the %d x %d raster",
                          p->rows, p->cols);

@@ -98,22 +98,32 @@ def make_track_params(grid_shape, move_dirn, memory_parameter=1, scaling_paramet
 THR_MAX_CELLS = 1 << 26        # the threshold table is addressed with 32-bit offsets
 
 
-def table_kind(table):
-    """'f64' | 'ring' | 'thr' | None for a tensor made by build_transition_table."""
+def table_kind(table, rows=None, cols=None):
+    """'f64' | 'ring' | 'thr' | None for a tensor made by build_transition_table.  The kind is the
+    tensor's dtype (float64 rows, float32 ring records, int32 threshold dwords), so it survives
+    clone / to / pickling; with rows, cols the size is checked against the library's layout."""
     if table is None:
         return None
-    if table.dtype == torch.float64:
-        return 'f64'
-    return getattr(table, '_ssrs_kind', 'ring')
+    kind = {torch.float64: 'f64', torch.float32: 'ring', torch.int32: 'thr'}.get(table.dtype)
+    if kind is None:
+        raise ValueError(f'a transition table is float64, float32 (ring) or int32 (threshold), not {table.dtype}')
+    if rows is not None:
+        want = {'f64': rows * cols * 8, 'ring': nat.lib().ssrs_transition_ring_bytes(rows, cols) // 4,
+                'thr': nat.lib().ssrs_transition_thr_bytes(rows, cols) // 4}[kind]
+        if table.numel() != want or not table.is_contiguous():
+            raise ValueError(f'this {table.dtype} tensor is not a {kind} table of a {rows} x {cols} raster '
+                             f'({table.numel()} elements, expected {want} contiguous)')
+    return kind
 
 
 def build_transition_table(updraft, potential, ring=False, thr=False, move_dirn=None):
     """Per-cell move weights for the table stepper: 8 x f64 per cell (any
     memory_parameter); with ring=True the f32 ring table (10 x f32 per cell, a
     1-D float32 tensor) of the three-candidate stepper; with thr=True the threshold table
-    (8 dwords per cell: the two 16-bit decision thresholds for each of the eight last moves) of the
-    threshold stepper -- it belongs to ONE heading, `move_dirn` (degrees).  Both f32 forms
-    serve memory_parameter 1 / nu 1 only."""
+    (8 dwords per cell: the two 16-bit decision thresholds for each of the eight last moves, a 1-D
+    int32 tensor) of the threshold stepper -- it belongs to ONE heading, `move_dirn` (degrees),
+    recorded in the table's header and checked by the stepper.  Both compact forms serve
+    memory_parameter 1 / nu 1 only."""
     upd = to_dev(updraft, torch.float64)
     pot = to_dev(potential, torch.float32)
     rows, cols = int(upd.shape[0]), int(upd.shape[1])
@@ -124,12 +134,12 @@ def build_transition_table(updraft, potential, ring=False, thr=False, move_dirn=
             raise ValueError('the threshold table needs move_dirn (it holds the prior fallback of that heading)')
         prior = np.ascontiguousarray(get_directional_probs(float(move_dirn) * np.pi / 180.), dtype=np.float64)
         nbytes = nat.lib().ssrs_transition_thr_bytes(rows, cols)
-        table = torch.empty(nbytes // 4, dtype=torch.float32, device=upd.device)
+        # int32: the kind travels with the tensor (the ring table is float32); the heading travels
+        # in the table's own header, which ssrs_tracks_simulate checks against its prior
+        table = torch.empty(nbytes // 4, dtype=torch.int32, device=upd.device)
         nat.check(nat.lib().ssrs_transition_thr_build(
             nat.ptr(upd), nat.ptr(pot), prior.ctypes.data_as(C.POINTER(C.c_double)), nat.ptr(table),
             rows, cols, stream_ptr()))
-        table._ssrs_kind = 'thr'
-        table._ssrs_dirn = float(move_dirn)
         return table
     if ring:
         nbytes = nat.lib().ssrs_transition_ring_bytes(rows, cols)
@@ -194,7 +204,8 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
     rasters (numpy or CUDA tensors); both None = 'drw'.  `table` (from
     build_transition_table) or use_table=True selects the one-fetch-per-step
     path; default: table when it pays (many steps per cell).  A float32
-    `table` is the ring table (build_transition_table(..., ring=True)); when the
+    `table` is the ring table (build_transition_table(..., ring=True)), an int32 one the
+    threshold table; when the
     table is built here, the threshold table (build_transition_table(..., thr=True)) is
     picked whenever it applies (memory 1, nu 1, rows * cols < 2^26); ring=True / thr=False
     ask for the ring table, ring=False for the f64 table.
@@ -236,10 +247,9 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
                 ring = f32_ok and not thr
             table = build_transition_table(upd, pot, ring=bool(ring) and not thr, thr=bool(thr),
                                            move_dirn=move_dirn)
-    is_thr = table_kind(table) == 'thr'
-    if is_thr and getattr(table, '_ssrs_dirn', float(move_dirn)) != float(move_dirn):
-        raise ValueError('this threshold table was built for another move_dirn')
-    is_ring = table is not None and table.dtype == torch.float32
+    kind = table_kind(table, rows, cols)
+    is_thr = kind == 'thr'
+    is_ring = kind in ('ring', 'thr')          # the f32 / dword family: default movement model only
     if is_ring and not ring_table_applies(memory_parameter, scaling_parameter, two_pass,
                                           exact_only, steps_per_launch):
         raise ValueError('the ring table needs memory_parameter 1, scaling_parameter 1, no '

@@ -362,7 +362,23 @@ class Simulator(Config):
         random key when the run is unseeded (sim_seed < 0)."""
         if self.sim_seed >= 0:
             return int(self.sim_seed) + int(real_id)
-        return int.from_bytes(os.urandom(7), 'little')
+        seed = int.from_bytes(os.urandom(7), 'little')
+        if self._shards_tracks():
+            # the shards of one case are ONE batch: every rank steps under rank 0's key (the items
+            # are prepared in the same order on every rank, so the broadcasts pair up)
+            seed = int(self._broadcast_int64([seed])[0])
+        return seed
+
+    def _broadcast_int64(self, values, src=0):
+        """`values` of rank `src` on every rank (an int64 array; the device follows the backend)."""
+        import torch.distributed as dist
+        arr = np.asarray(values, dtype=np.int64)
+        if not (self._dist_on() and dist.get_world_size() > 1):
+            return arr
+        dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
+        t = torch.from_numpy(arr.copy()).to(dev)
+        dist.broadcast(t, src=src)
+        return t.cpu().numpy()
 
     # device-resident forms of load_updrafts / get_directional_potential: the public methods
     # keep the reference's numpy-in / numpy-out contract, the stepper takes these
@@ -421,7 +437,11 @@ class Simulator(Config):
         starts = np.stack([starting_rows, starting_cols], 1).astype(np.int32)
         use_table = {'auto': None, 'table': True, 'direct': False}[self.stepper_path]
         self.last_stats = {}
+        self.last_seeds = {}
         sharded = self._shards_tracks()
+        if sharded and self.sim_seed < 0:
+            # unseeded: every rank drew its own start cells; the batch is rank 0's
+            starts = self._broadcast_int64(starts).astype(np.int32)
         lo, hi = 0, len(starts)
         if sharded:
             from .distributed import shard_range
@@ -448,6 +468,7 @@ class Simulator(Config):
 
         def run(item):
             case_id, real_id, fields, seed = item
+            self.last_seeds[(case_id, real_id)] = seed
             id_str = self._get_id_string(case_id, real_id)
             start_time = time.time()
             with torch.cuda.stream(torch.cuda.Stream()):

@@ -18,6 +18,9 @@ def build(mode, out_dir, run_name):
                 track_direction=0.)
     if mode == 'uniform':
         return Simulator(Config(**base), terrain='synthetic')
+    if mode == 'unseeded':            # uniform mode without a seed: the ranks must agree on rank 0's draws
+        base['sim_seed'] = -1
+        return Simulator(Config(**base), terrain='synthetic')
     if mode == 'snapshot':
         x, y, ws, wd = wind_lattice((8., 6.), 2.0)
         return Simulator(Config(sim_mode='snapshot', **base), terrain='synthetic',
@@ -40,9 +43,15 @@ def main():
     os.environ['MASTER_PORT'] = port
     torch.cuda.set_device(0)
     if world > 1:
-        dist.init_process_group('gloo', rank=rank, world_size=world)
+        # a lost peer must fail this rank fast (non-zero exit), not park it for the default 30 minutes
+        from datetime import timedelta
+        dist.init_process_group('gloo', rank=rank, world_size=world, timeout=timedelta(seconds=180))
     sim = build(mode, out_dir, f'{mode}_w{world}')
     sim.simulate_tracks()
+    if mode == 'unseeded':
+        import json
+        with open(os.path.join(out_dir, f'seeds_w{world}_r{rank}.json'), 'w') as f:
+            json.dump(sorted((list(k), v) for k, v in sim.last_seeds.items()), f)
     sim.compute_presence_map(radius=300.)
     if world > 1:
         dist.barrier()

@@ -56,7 +56,7 @@ def test_integration_md_stub_runs_and_matches_oracle(gpu):
     prm.prior[:] = [float(v) for v in orc.get_directional_probs(track_direction * np.pi / 180.)]
     upd, pot = dev(updraft, torch.float64), dev(potential, torch.float32)
     lib.ssrs_transition_thr_bytes.restype = C.c_size_t
-    table = torch.empty(lib.ssrs_transition_thr_bytes(rows, cols) // 4, dtype=torch.float32, device='cuda')
+    table = torch.empty(lib.ssrs_transition_thr_bytes(rows, cols) // 4, dtype=torch.int32, device='cuda')
     ok(lib.ssrs_transition_thr_build(p(upd), p(pot), prm.prior, p(table), rows, cols, STREAM()))
     prm.flags |= 128                                        # SSRS_TRACKS_THR_TABLE
     starts = dev(np.stack([starting_rows, starting_cols], 1), torch.int32)

@@ -788,6 +788,24 @@ def test_thr_table_belongs_to_one_heading(gpu):
         movmodel.simulate_tracks(90., [[5, 5]], (40, 50), 1, 1., upd, pot, table=table)
     with pytest.raises(ValueError):
         movmodel.build_transition_table(upd, pot, thr=True)
+    # the kind and the heading travel IN the table (dtype / header in the guard band), not in Python
+    # attributes: a clone is still a threshold table of heading 0 and nothing else
+    import torch
+    copy = table.clone()
+    assert movmodel.table_kind(copy, 40, 50) == 'thr'
+    ref = movmodel.simulate_tracks(0., [[5, 5], [7, 20]], (40, 50), 1, 1., upd, pot, table=table, seed=4)
+    got = movmodel.simulate_tracks(0., [[5, 5], [7, 20]], (40, 50), 1, 1., upd, pot, table=copy, seed=4)
+    assert torch.equal(ref.lengths, got.lengths) and torch.equal(ref.hist, got.hist)
+    with pytest.raises(ValueError, match='threshold table'):
+        movmodel.simulate_tracks(90., [[5, 5]], (40, 50), 1, 1., upd, pot, table=copy)
+    with pytest.raises(ValueError):           # the dwords seen as floats are not a ring table of this raster
+        movmodel.simulate_tracks(0., [[5, 5]], (40, 50), 1, 1., upd, pot, table=copy.view(torch.float32))
+    ring = movmodel.build_transition_table(upd, pot, ring=True)
+    with pytest.raises(ValueError):           # nor is a ring table a threshold table
+        movmodel.simulate_tracks(0., [[5, 5]], (40, 50), 1, 1., upd, pot, table=ring.clone().view(torch.int32))
+    with pytest.raises(ValueError):           # a table of another raster
+        movmodel.simulate_tracks(0., [[5, 5]], (40, 48), 1, 1., np.ascontiguousarray(upd[:, :48]),
+                                 np.ascontiguousarray(pot[:, :48]), table=copy)
 
 
 def test_one_band_batch_is_redealt_over_the_lists(gpu):

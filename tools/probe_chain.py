@@ -38,6 +38,7 @@ rows = []
 for name, tag in libs:
     env = dict(os.environ)
     if tag:
+        env['SSRS_ALLOW_PROBE_LIB'] = '1'
         env['SSRS_HIP_LIB'] = os.path.join(ROOT, 'ssrs_amd', f'libssrs_probe_{tag}.so')
     p = subprocess.run([sys.executable, os.path.abspath(__file__), 'child'], env=env, capture_output=True, text=True)
     line = [l for l in p.stdout.splitlines() if l.startswith('RESULT ')]
