@@ -1,14 +1,23 @@
 #!/usr/bin/env python3
 """Headline benchmark (BASELINE.json): simulated tracks/s + updraft-raster
 Mcells/s on the 60x50 km @10 m uniform-mode raster (5000 x 6000 cells),
-100k tracks per MI355X.
+100k tracks per MI355X, through the potential field of the build's own solver
+("from the build's solver if landed"; /root/reference/ssrs/simulator.py:259-288
+computes it before the tracks are mapped, :360-369).
 
 One "step" = one pass of the hot path over one batch of synthetic input, with
 every input already resident in HBM:
     DEM --K1 fused raster--> orograph f32 + usable updraft f64
         --K2a--> per-cell transition table (updraft x potential)
         --K2b/K3--> 100k tracks stepped to completion + uint32 presence histogram
-        [N > 1: one RCCL sum-reduce of the histogram to rank 0]
+        [N > 1: one RCCL sum-reduce of the histogram to rank 0, widened to 64 bits when needed]
+The potential is solved ONCE, outside the timed region (the reference caches it on disk,
+simulator.py:266-272).  On this field ~44 % of the tracks reach a basin and circle there until
+max_moves = 7.5e6 (reference behaviour, tests/golden/g11_wander.npz): a pass is ~2.6e11 steps, and the
+figure of merit beside tracks/s is steps/s.  The linear-ramp stand-in potential of rounds 1-2
+(a batch that crosses the raster as one front, 4 850 steps per track) is kept as the labelled
+secondary object `stand_in`.
+
 Tracks shard over ranks by global track id (weak scaling: 100k tracks per GPU).
 
 Launch: `python bench.py` (1 GPU) or
@@ -32,13 +41,17 @@ STEP_BYTES = 76                 # 9x4 + 9x4 window + 4 B point/R
 RASTER_BYTES_PER_CELL = 20      # fused K1 as benchmarked: f64 DEM in (8) + f32 out (4)
 #                                 + f64 usable out (8); SURVEY's 12 B/cell figure is
 #                                 the f32-in/f32-out elementwise kernel
+# steps/s of the stepper once the GPU is FULL of waves (1 M tracks per GPU on the ramp, every SIMD
+# holding several waves: profiles/r02_scale_tracks.txt, 40.6 M tracks/s x 4 850 steps): what a
+# latency-bound batch of 100k tracks is measured against (`throughput_frac`)
+THROUGHPUT_BOUND_STEPS_PER_S = 2.0e11
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--tracks', type=int, default=100_000, help='tracks per GPU')
     ap.add_argument('--resolution', type=float, default=10.0)
     ap.add_argument('--width-km', type=float, nargs=2, default=(60.0, 50.0))
@@ -46,14 +59,17 @@ def parse():
     ap.add_argument('--steps-per-launch', type=int, default=0)
     ap.add_argument('--cpu-seconds', type=float, default=20.0,
                     help='target CPU time of the cpu_baseline sample (0 = skip)')
-    ap.add_argument('--potential', default='ramp', choices=['ramp', 'solve'])
+    ap.add_argument('--cpu-cap', type=int, default=60_000,
+                    help='max_moves of the cpu_baseline sample on the solved field (the GPU repeats the '
+                         'sample under the same cap for the in-run parity check)')
+    ap.add_argument('--potential', default='solve', choices=['ramp', 'solve'])
     ap.add_argument('--solve-iterations', type=int, default=2000)
-    ap.add_argument('--solved-tracks', type=int, default=10_000,
-                    help='tracks of the solved_potential leg (outside the timed region; 0 = skip)')
+    ap.add_argument('--stand-in-steps', type=int, default=10,
+                    help='timed passes of the ramp stand-in leg (after the timed region; 0 = skip)')
     ap.add_argument('--no-chain-probe', action='store_true',
                     help='skip the 16 384-track dependent-chain measurement (profiling runs: keeps per-kernel averages clean)')
-    ap.add_argument('--ref-cpu-tracks', type=int, default=3,
-                    help='tracks of the reference-equivalent (numpy restatement) CPU rate (0 = skip)')
+    ap.add_argument('--ref-cpu-seconds', type=float, default=2.0,
+                    help='seconds of stepping of the reference-equivalent (numpy restatement) CPU rate (0 = skip)')
     ap.add_argument('--no-binning', action='store_true', help='per-step global atomics for the histogram')
     ap.add_argument('--no-schedule', action='store_true', help='disable the coherent schedule')
     ap.add_argument('--exact-only', action='store_true', help='disable the fast decision path')
@@ -64,55 +80,91 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(args, gridsize, dem, pot, starts, seed, steps_per_track):
-    """Oracle (C port of the reference algorithm, OpenMP) on the host cores, on
-    a bounded sample of the same workload: the full-grid raster once and the
-    first M tracks (same global ids / Philox streams as the GPU run)."""
+def host_cpu():
+    """CPU model, physical cores and hardware threads of the box (printed beside the baseline)."""
+    model, cores = None, set()
+    try:
+        phys = core = None
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name') and model is None:
+                    model = line.split(':', 1)[1].strip()
+                elif line.startswith('physical id'):
+                    phys = line.split(':', 1)[1].strip()
+                elif line.startswith('core id'):
+                    core = line.split(':', 1)[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        cores.add((phys, core))
+                    phys = core = None
+    except OSError:
+        pass
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    return model, (len(cores) or None), threads
+
+
+def cpu_baseline(args, gridsize, dem_h, upd_gpu_h, pot_h, starts, seed, cap):
+    """Oracle (C port of the reference algorithm, OpenMP) on the host cores, on a bounded sample of
+    the same workload: the full-grid raster chain once and the first M tracks (same global ids /
+    Philox streams as the GPU run), every track capped at `cap` moves when given (on the solved
+    field a track that reaches a basin would otherwise take 7.5e6: ~4 core-minutes each).  The
+    stepping sample reads the GPU's own usable-updraft raster, so that its lengths and histogram
+    can be compared bit for bit with a GPU run of the same sample under the same cap."""
     from oracle import c_oracle
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    model, phys_cores, threads = host_cpu()
     t0 = time.perf_counter()
-    slope, aspect = c_oracle.slope_aspect(dem, args.resolution)
+    slope, aspect = c_oracle.slope_aspect(dem_h, args.resolution)
     _, oro32 = c_oracle.orographic(slope, aspect, 10.0, 270.0)
     upd = c_oracle.threshold(oro32, 0.75)
     t_raster = time.perf_counter() - t0
+    same_cells = float(np.mean(upd == upd_gpu_h))
+    del slope, aspect, oro32, upd
     # calibrate, then size the sample for ~cpu_seconds of stepping
     t0 = time.perf_counter()
-    cal = c_oracle.simulate_tracks(0.0, starts[:2 * cores], gridsize, 1, 1.0, upd, pot,
-                                   seed=seed, want_traj=False, want_hist=True, nthreads=cores)
+    cal = c_oracle.simulate_tracks(0.0, starts[:2 * threads], gridsize, 1, 1.0, upd_gpu_h, pot_h,
+                                   seed=seed, want_traj=False, want_hist=True, nthreads=threads, max_moves=cap)
     t_cal = max(time.perf_counter() - t0, 1e-6)
     rate = cal['steps'] / t_cal
-    m = int(min(len(starts), max(2 * cores, rate * args.cpu_seconds / max(steps_per_track, 1))))
+    per_track = max(cal['steps'] / (2 * threads), 1.0)
+    m = int(min(len(starts), max(2 * threads, rate * args.cpu_seconds / per_track)))
     t0 = time.perf_counter()
-    run = c_oracle.simulate_tracks(0.0, starts[:m], gridsize, 1, 1.0, upd, pot, seed=seed,
-                                   want_traj=False, want_hist=True, nthreads=cores)
+    run = c_oracle.simulate_tracks(0.0, starts[:m], gridsize, 1, 1.0, upd_gpu_h, pot_h, seed=seed,
+                                   want_traj=False, want_hist=True, nthreads=threads, max_moves=cap)
     t_run = time.perf_counter() - t0
     ref_equiv = None
-    if args.ref_cpu_tracks > 0:
+    if args.ref_cpu_seconds > 0:
         # the reference's own arithmetic speed: the numpy restatement (oracle/ssrs_oracle.py, the
         # same per-step numpy calls as /root/reference/ssrs/movmodel.py:264-318, which cannot travel)
         from oracle import ssrs_oracle as orc
         from oracle.philox import TrackUniforms
         t0 = time.perf_counter()
-        nsteps = 0
-        for t in range(args.ref_cpu_tracks):
-            tr = orc.generate_simulated_tracks(0.0, (int(starts[t, 0]), int(starts[t, 1])), gridsize, 1, 1.0,
-                                               upd, pot, uniform=TrackUniforms(seed, t))
+        nsteps = ntr = 0
+        ref_cap = min(cap or 20_000, 20_000)
+        while time.perf_counter() - t0 < args.ref_cpu_seconds and ntr < m:
+            tr = orc.generate_simulated_tracks(0.0, (int(starts[ntr, 0]), int(starts[ntr, 1])), gridsize, 1, 1.0,
+                                               upd_gpu_h, pot_h, uniform=TrackUniforms(seed, ntr), max_moves=ref_cap)
             nsteps += len(tr) - 1
-            assert len(tr) == run['lengths'][t], 'numpy restatement and C port disagree'
+            assert len(tr) == min(int(run['lengths'][ntr]), ref_cap + 1), 'numpy restatement and C port disagree'
+            ntr += 1
         t_ref = time.perf_counter() - t0
-        ref_equiv = {'steps_per_s_per_core': nsteps / t_ref, 'cores': 1, 'tracks': args.ref_cpu_tracks,
-                     'steps': nsteps, 'seconds': t_ref,
+        ref_equiv = {'steps_per_s_per_core': nsteps / t_ref, 'cores': 1, 'tracks': ntr,
+                     'steps': nsteps, 'seconds': t_ref, 'max_moves_cap': ref_cap,
                      'what': 'numpy restatement of generate_simulated_tracks, one process, first tracks of '
                              'this workload; SURVEY measured 12.1 k steps/s/core for the reference itself'}
     return {
-        'value': m / t_run, 'unit': 'tracks/s', 'cores': cores, 'kind': 'port',
+        'value': m / t_run, 'unit': 'tracks/s', 'cores': threads, 'kind': 'port',
+        'cpu_model': model, 'physical_cores': phys_cores, 'hardware_threads_used': threads,
+        'max_moves_cap': cap,
         'reference_equivalent': ref_equiv,
-        'sample': (f'C/OpenMP oracle port, first {m} of the {len(starts)} tracks of this '
-                   f'workload ({run["steps"]} steps in {t_run:.1f} s) on {cores} host threads; '
-                   f'raster chain on the full grid once ({t_raster:.1f} s)'),
+        'sample': (f'C/OpenMP oracle port, first {m} of the {len(starts)} tracks of this workload'
+                   + (f', every track capped at {cap} moves' if cap else '')
+                   + f' ({run["steps"]} steps in {t_run:.1f} s) on {threads} host threads'
+                   + (f' ({phys_cores} physical cores, {model})' if phys_cores else '')
+                   + f'; raster chain on the full grid once ({t_raster:.1f} s)'),
         'steps_per_s': run['steps'] / t_run,
-        'steps_per_s_per_core': run['steps'] / t_run / cores,
+        'steps_per_s_per_core': run['steps'] / t_run / threads,
         'raster_mcells_per_s': gridsize[0] * gridsize[1] / t_raster / 1e6,
+        'raster_cells_identical_to_gpu': same_cells,
     }, run, m
 
 
@@ -126,7 +178,7 @@ def build_table(args, movmodel, upd, pot):
 
 def chain_probe(args, movmodel, layers, dem, pot, starts_h, gridsize, res, seed):
     """What bounds the stepper: one step of a track is a chain of dependent instructions
-    (Philox -> decision -> next address -> 12-byte gather -> ...).  A batch of 16 384 tracks is
+    (Philox -> decision -> next address -> gather -> ...).  A batch of 16 384 tracks is
     one wave per CU, nothing to overlap with: launch time / steps = the chain's latency.  The
     full batch (1.5 waves per SIMD) cannot run a launch faster than S x that latency."""
     import torch
@@ -148,51 +200,167 @@ def chain_probe(args, movmodel, layers, dem, pot, starts_h, gridsize, res, seed)
         best = us if best is None else min(best, us)
     return {'tracks': n, 'us_per_step_lone_wave': best,
             'launch_floor_ms': None if best is None else best * (args.steps_per_launch or 512) / 1e3,
+            'potential': 'ramp stand-in',
             'what': 'average launch duration / steps per launch of a 16 384-track batch (one wave per CU, no '
                     'histogram): the latency of one step\'s dependent chain, an upper bound (late launches are '
                     'shallower than S steps)'}
 
 
-def solved_leg(args, movmodel, layers, dem, starts_h, gridsize, res, seed):
-    """The same workload on the potential of the build's own solver, outside the
-    timed region and on a bounded batch: on this DEM about 44 % of the tracks reach a basin of
-    the field, circle there and stop at max_moves = 7.5e6 (reference behaviour, pinned at 50 m by
-    tests/golden/g11_wander.npz), so 100k tracks take ~12 s per pass."""
-    import torch
-    import warnings
-    from ssrs_amd.potential import solve_potential
-    _, upd = layers.updraft_from_dem(dem, res, 10.0, 270.0, threshold=0.75)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        pot, sst = solve_potential(upd, 0.0, max_iterations=args.solve_iterations, return_stats=True)
-    torch.cuda.synchronize()
-    t_solve = time.perf_counter() - t0
-    n = min(args.solved_tracks, len(starts_h))
-    sub = torch.from_numpy(starts_h[:n]).to(dem.device)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    table = build_table(args, movmodel, upd, pot)
-    o = movmodel.simulate_tracks(0.0, sub, gridsize, 1, 1.0, upd, pot, seed=seed, table=table, profile=True)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    L = o.lengths.cpu().numpy() - 1
-    mm = gridsize[0] // 2 * (gridsize[1] // 2)
-    assert int(o.hist.sum().item()) == o.stats['total_steps'] + n, 'histogram checksum failed (solved leg)'
+class Passes:
+    """K timed passes of the hot path on one potential field (the main leg and the stand-in leg)."""
+
+    def __init__(self, args, mods, dem, pot, starts, lo, gridsize, res, seed, world, dev):
+        import torch
+        self.args, self.dem, self.pot, self.starts, self.lo = args, dem, pot, starts, lo
+        self.layers, self.movmodel, self.reduce_histogram = mods
+        self.gridsize, self.res, self.seed, self.world = gridsize, res, seed, world
+        # two histograms: the RCCL reduce of step i runs under the kernels of step i + 1
+        self.hists = [torch.zeros(gridsize, dtype=torch.int32, device=dev) for _ in range(2 if world > 1 else 1)]
+        self.pending = [None] * len(self.hists)
+        self.reduced = [None] * len(self.hists)
+        self.step_no = 0
+        self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        self.acc = dict(raster_ms=0.0, table_ms=0.0, step_kernel_ms=0.0, step_wall_ms=0.0, hist_ms=0.0, steps=0,
+                        launches=0, timed_launches=0, first_move_ms=0.0, block_window_ms=0.0, block_window_timed=0,
+                        block_window_steps=0, block_window_launches=0, window_launches=0, tile_launches=0,
+                        wander_sorts=0)
+
+    def one_step(self, timed):
+        args, ev, acc = self.args, self.ev, self.acc
+        slot = self.step_no % len(self.hists)
+        self.step_no += 1
+        hist = self.hists[slot]
+        if self.pending[slot] is not None:        # this buffer's previous reduce (two steps ago)
+            self.pending[slot].wait()
+            self.pending[slot] = None
+        hist.zero_()
+        ev[0].record()
+        oro, upd = self.layers.updraft_from_dem(self.dem, self.res, 10.0, 270.0, threshold=0.75)
+        ev[1].record()
+        table = None if args.direct else build_table(args, self.movmodel, upd, self.pot)
+        ev[2].record()
+        out = self.movmodel.simulate_tracks(0.0, self.starts, self.gridsize, 1, 1.0, upd, self.pot, seed=self.seed,
+                                            track_id_base=self.lo, table=table, use_table=not args.direct,
+                                            hist=hist, steps_per_launch=args.steps_per_launch,
+                                            profile=True, exact_only=args.exact_only,
+                                            schedule=not args.no_schedule, binning=not args.no_binning)
+        # (widens to 64 bits by itself when the ranks' largest counts could wrap a 32-bit sum)
+        self.pending[slot] = self.reduce_histogram(hist, dst=0, async_op=True)
+        self.reduced[slot] = self.pending[slot].result if self.pending[slot] is not None else hist
+        ev[3].record()
+        if timed:
+            # simulate_tracks returned after its last launch completed, so the
+            # events are final; no device-wide sync (it would wait for the reduce)
+            ev[2].synchronize()
+            acc['raster_ms'] += ev[0].elapsed_time(ev[1])
+            acc['table_ms'] += ev[1].elapsed_time(ev[2])
+            st = out.stats
+            acc['step_kernel_ms'] += st['kernel_ms']
+            acc['step_wall_ms'] += st['wall_ms']
+            acc['hist_ms'] += st['hist_ms']
+            acc['steps'] += st['total_steps']
+            for k in ('launches', 'timed_launches', 'first_move_ms', 'block_window_ms', 'block_window_timed',
+                      'block_window_steps', 'block_window_launches', 'window_launches', 'tile_launches', 'wander_sorts'):
+                acc[k] += st.get(k, 0)
+        return out
+
+    def drain(self):
+        for i, w in enumerate(self.pending):
+            if w is not None:
+                w.wait()
+                self.pending[i] = None
+
+    def run(self, steps, warmup):
+        import torch
+        import torch.distributed as dist
+        for _ in range(warmup):
+            self.one_step(False)
+        self.drain()
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        last = None
+        for _ in range(steps):
+            last = self.one_step(True)
+        self.drain()                                  # every step's reduce is inside the timed region
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        self.last_hist = self.reduced[(self.step_no - 1) % len(self.hists)]
+        return elapsed, last
+
+
+def stepper_roofline(args, acc, K, solved):
+    """`roofline` of the pass's dominant kernel, from HIP events the library records around every
+    stepper launch on the launch stream (SSRS_TRACKS_PROFILE)."""
+    kernel_s = acc['step_kernel_ms'] / 1e3
+    # bytes the chosen data path really requests per step (window gathers 18 x 4 + 4; f64 table row
+    # 64 + 24 + 4; f64 three candidates 24 + 4; ring triple 12 + 4; threshold dword 4 + a 4-byte
+    # visit / 4 and an LDS add in block-window launches)
+    table_path = not (args.direct or args.f64_table or args.exact_only or args.ring_table)
+    moved_bytes = 76 if args.direct else (92 if args.exact_only else (28 if args.f64_table else (16 if args.ring_table else 8)))
+    bw_share = acc['block_window_ms'] / acc['step_kernel_ms'] if acc['step_kernel_ms'] > 0 else 0.0
+    if solved and table_path and bw_share > 0.5:
+        # the pass is dominated by the block-window launches of the roaming survivors: one 4-byte
+        # table entry per step, the visit is counted in LDS
+        ms, steps, n = acc['block_window_ms'], acc['block_window_steps'], acc['block_window_timed']
+        bytes_per_step = 4
+        name = 'k_step_thr<6, false, true> (K2 stepper, block histogram windows; rank 0)'
+    else:
+        first_moves = K if acc['first_move_ms'] > 0 else 0
+        n = acc['timed_launches'] - first_moves
+        ms = acc['step_kernel_ms'] - acc['first_move_ms']
+        steps = acc['steps']
+        bytes_per_step = moved_bytes
+        name = ('k_step_tracks' if (args.direct or args.f64_table or args.exact_only)
+                else ('k_step_lean<ring>' if args.ring_table else 'k_step_thr<4, true, false>')) + ' (K2 stepper, rank 0)'
+    sec = ms / 1e3
+    gbps = steps * bytes_per_step / sec / 1e9 if sec > 0 else 0.0
+    model = steps * STEP_BYTES / sec / 1e9 if sec > 0 else 0.0
+    sps = steps / sec if sec > 0 else 0.0
     return {
-        'tracks': n, 'tracks_per_s': n / dt, 'steps_per_s': o.stats['total_steps'] / dt, 'seconds': dt,
-        'steps_per_track_mean': float(L.mean()), 'steps_per_track_median': float(np.median(L)),
-        'steps_per_track_max': int(L.max()), 'share_at_max_moves': float(np.mean(L >= mm)), 'max_moves': mm,
-        'launches': o.stats['launches'], 'window_launches': o.stats['window_launches'],
-        'tile_launches': o.stats['tile_launches'], 'block_window_launches': o.stats['block_window_launches'],
-        'solver': {'iterations': sst['iterations'], 'residual': sst['residual'], 'converged': sst['converged'],
-                   'seconds': t_solve, 'rel_tol': 1e-15, 'amg_levels': sst['amg_levels'],
-                   'setup_ms': sst.get('setup_ms'), 'workspace_used_gb': round(sst.get('workspace_used', 0) / 1e9, 2),
-                   'workspace_reserved_gb': round(sst.get('workspace_bytes', 0) / 1e9, 2)},
-        'what': 'first tracks of the same start list through ssrs_potential_solve\'s field (library default '
-                'tolerance), one pass, table build included; not part of `value`',
-    }
+        'kernel': name,
+        # what bounds it: the dependent chain of one step (gather -> decode -> next address), not HBM
+        'bound': 'latency',
+        # achieved = bytes the shipped data path really requests per step x steps / sum of this
+        # kernel's launch durations
+        'achieved': gbps, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': gbps / HBM_PEAK_GBPS,
+        'traffic': None,
+        'bytes_per_step': bytes_per_step,
+        'launches': n // max(K, 1), 'avg_launch_ms': ms / max(n, 1),
+        'avg_bytes_per_launch': steps * bytes_per_step / max(n, 1),
+        'share_of_stepper_time': (ms / acc['step_kernel_ms']) if acc['step_kernel_ms'] > 0 else None,
+        'steps_per_s_in_kernel': sps,
+        # the number that can approach 1: steps/s of this kernel against the stepper's measured rate
+        # with the GPU full of waves (a latency-bound batch leaves SIMDs idle)
+        'throughput_frac': sps / THROUGHPUT_BOUND_STEPS_PER_S,
+        'throughput_bound_steps_per_s': THROUGHPUT_BOUND_STEPS_PER_S,
+        'first_move_launch_ms': acc['first_move_ms'] / max(K, 1),
+        # SURVEY 8(d)'s 76 B/step is the gather volume of the REFERENCE's formulation (18 window
+        # reads + 1 point); the shipped path precomputes the windows into a table, so this
+        # figure can exceed the peak and is not a roofline fraction
+        'model_bytes_per_step': STEP_BYTES, 'model_gbps': model, 'model_frac': model / HBM_PEAK_GBPS,
+    }, kernel_s
+
+
+def attach_traffic(roof, variant_ok):
+    """HBM bytes per launch from the PMC passes (profiles/, separate --pmc runs): only quoted when
+    THIS run is the configuration those passes profiled, and labelled as a profile constant."""
+    pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if not (os.path.exists(pmc) and variant_ok):
+        return
+    try:
+        with open(pmc) as f:
+            rec = json.load(f)
+        key = 'solved' if '<6' in roof['kernel'] else 'ramp'
+        ent = rec.get(key)
+        if ent:
+            roof['traffic'] = ent.get('bytes_per_launch')
+            roof['traffic_source'] = 'profile constant (not counted in this run): ' + str(ent.get('source'))
+    except Exception:
+        pass
 
 
 def main():
@@ -233,6 +401,7 @@ def main():
     ncells = rows * cols
     seed = 30
     n_total = args.tracks * world
+    max_moves = int(np.ceil(rows / 2 * cols / 2))
     # identical on every rank: replicated rasters, global start list
     dem_h = synthetic_dem(gridsize, res, noise=args.dem_noise)
     np.random.seed(seed)
@@ -243,87 +412,39 @@ def main():
     dev = torch.device('cuda', local_rank)
     dem = torch.from_numpy(dem_h).to(dev)
     starts = torch.from_numpy(starts_h[lo:hi]).to(dev)
-    if args.potential == 'solve':
+    solved = args.potential == 'solve'
+    ramp = torch.from_numpy(ramp_potential(gridsize)).to(dev)
+    ramp_label = ('LABELLED STAND-IN: linear ramp 1000(1-r/(R-1)) (exact solution for '
+                  'uniform conductance); the reference spsolve is infeasible at 3e7 cells')
+    solver = None
+    if solved:
         from ssrs_amd.potential import solve_potential
         _, upd0 = layers.updraft_from_dem(dem, res, 10.0, 270.0, threshold=0.75)
         import warnings
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
             pot, sst = solve_potential(upd0, 0.0, max_iterations=args.solve_iterations,
                                        return_stats=True)      # library default rel_tol (1e-15)
-        pot_label = (f'ssrs_potential_solve (AMG-PCG): {sst["iterations"]} iterations, |r|/|b| = '
-                     f'{sst["residual"]:.1e}, {sst["kernel_ms"] / 1e3:.0f} s (outside the timed region)')
+        torch.cuda.synchronize()
+        t_solve = time.perf_counter() - t0
+        pot_label = (f'ssrs_potential_solve (K5, aggregation AMG + PCG, default tolerance 1e-15): {sst["iterations"]} '
+                     f'iterations, |r|/|b| = {sst["residual"]:.1e}, {t_solve:.1f} s, once, outside the timed region '
+                     f'(the reference caches the field on disk, simulator.py:266-272)')
+        solver = {'iterations': sst['iterations'], 'residual': sst['residual'], 'converged': sst['converged'],
+                  'seconds': t_solve, 'rel_tol': 1e-15, 'amg_levels': sst['amg_levels'], 'setup_ms': sst.get('setup_ms'),
+                  'workspace_used_gb': round(sst.get('workspace_used', 0) / 1e9, 2),
+                  'workspace_reserved_gb': round(sst.get('workspace_bytes', 0) / 1e9, 2)}
         del upd0
     else:
-        pot = torch.from_numpy(ramp_potential(gridsize)).to(dev)
-        pot_label = ('LABELLED STAND-IN: linear ramp 1000(1-r/(R-1)) (exact solution for '
-                     'uniform conductance); the reference spsolve is infeasible at 3e7 cells')
-    # two histograms: the RCCL reduce of step i runs under the kernels of step i + 1
-    hists = [torch.zeros(gridsize, dtype=torch.int32, device=dev) for _ in range(2 if world > 1 else 1)]
-    pending = [None] * len(hists)
-    step_no = [0]
+        pot, pot_label = ramp, ramp_label
 
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    acc = dict(raster_ms=0.0, table_ms=0.0, step_kernel_ms=0.0, step_wall_ms=0.0,
-               hist_ms=0.0, steps=0, launches=0)
-
-    def one_step(timed):
-        slot = step_no[0] % len(hists)
-        step_no[0] += 1
-        hist = hists[slot]
-        if pending[slot] is not None:        # this buffer's previous reduce (two steps ago)
-            pending[slot].wait()
-            pending[slot] = None
-        hist.zero_()
-        ev[0].record()
-        oro, upd = layers.updraft_from_dem(dem, res, 10.0, 270.0, threshold=0.75)
-        ev[1].record()
-        table = None if args.direct else build_table(args, movmodel, upd, pot)
-        ev[2].record()
-        out = movmodel.simulate_tracks(0.0, starts, gridsize, 1, 1.0, upd, pot, seed=seed,
-                                       track_id_base=lo, table=table, use_table=not args.direct,
-                                       hist=hist, steps_per_launch=args.steps_per_launch,
-                                       profile=True, exact_only=args.exact_only,
-                                       schedule=not args.no_schedule, binning=not args.no_binning)
-        pending[slot] = reduce_histogram(hist, dst=0, async_op=True)
-        ev[3].record()
-        if timed:
-            # simulate_tracks returned after its last launch completed, so the
-            # events are final; no device-wide sync (it would wait for the reduce)
-            ev[2].synchronize()
-            acc['raster_ms'] += ev[0].elapsed_time(ev[1])
-            acc['table_ms'] += ev[1].elapsed_time(ev[2])
-            acc['step_kernel_ms'] += out.stats['kernel_ms']
-            acc['step_wall_ms'] += out.stats['wall_ms']
-            acc['hist_ms'] += out.stats['hist_ms']
-            acc['steps'] += out.stats['total_steps']
-            acc['launches'] += out.stats['launches']
-            acc['timed_launches'] = acc.get('timed_launches', 0) + out.stats.get('timed_launches', out.stats['launches'])
-            acc['first_move_ms'] = acc.get('first_move_ms', 0.0) + out.stats.get('first_move_ms', 0.0)
-        return out
-
-    def drain():
-        for i, w in enumerate(pending):
-            if w is not None:
-                w.wait()
-                pending[i] = None
-
-    for _ in range(args.warmup):
-        one_step(False)
-    drain()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    last = None
-    for _ in range(args.steps):
-        last = one_step(True)
-    drain()                                  # every step's reduce is inside the timed region
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    hist = hists[(step_no[0] - 1) % len(hists)]
-    elapsed = time.perf_counter() - t0
+    mods = (layers, movmodel, reduce_histogram)
+    main_leg = Passes(args, mods, dem, pot, starts, lo, gridsize, res, seed, world, dev)
+    elapsed, last = main_leg.run(args.steps, args.warmup)
+    acc = main_leg.acc
+    hist = main_leg.last_hist
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -341,19 +462,12 @@ def main():
 
     K = args.steps
     lengths = last.lengths.cpu().numpy()
-    steps_per_track = float(lengths.mean() - 1)
-    # checksum of checksums: every trajectory point was counted exactly once
-    assert int(hist.sum().item()) == total_steps_all // K + n_total, 'histogram checksum failed'
-    kernel_s = acc['step_kernel_ms'] / 1e3
-    first_moves = K if acc.get('first_move_ms', 0.0) > 0 else 0
-    main_launches = acc.get('timed_launches', acc['launches']) - first_moves
-    main_kernel_ms = acc['step_kernel_ms'] - acc.get('first_move_ms', 0.0)
-    # bytes the chosen data path really requests per step (read + 4 B visit / histogram update)
-    # (window gathers 18 x 4 + 4; f64 table row 64 + 24 + 4; f64 three candidates 24 + 4; ring triple
-    # 12 + 4; threshold dword 4 + 4)
-    moved_bytes = 76 if args.direct else (92 if args.exact_only else (28 if args.f64_table else (16 if args.ring_table else 8)))
-    achieved = acc['steps'] * STEP_BYTES / kernel_s / 1e9 if kernel_s > 0 else 0.0
-    moved_gbps = acc['steps'] * moved_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0
+    L = lengths.astype(np.int64) - 1
+    # checksum of checksums: every trajectory point was counted exactly once (the widened sum of a
+    # multi-rank run is int64; a single rank's uint32 counts are summed as such)
+    hsum = int(hist.sum().item()) if hist.dtype == torch.int64 else int((hist.view(torch.int32).to(torch.int64) & 0xFFFFFFFF).sum().item())
+    assert hsum == total_steps_all // K + n_total, 'histogram checksum failed'
+    roof, kernel_s = stepper_roofline(args, acc, K, solved)
     raster_s = acc['raster_ms'] / 1e3 / K
     out = {
         'metric': 'simulated tracks/sec (whole node)',
@@ -373,8 +487,8 @@ def main():
                          + ('' if args.dem_noise == 1.5 else f', DEM noise sigma {args.dem_noise:g} m')),
             'tracks_total': n_total,
             'parallelism': f'track-sharded x{world}, replicated rasters'
-                           + (f', {"RCCL" if backend == "nccl" else backend} histogram reduce (async, under the next step)'
-                              if world > 1 else ''),
+                           + (f', {"RCCL" if backend == "nccl" else backend} histogram reduce (async, under the next step; '
+                              f'64-bit when the ranks\' counts could wrap 32)' if world > 1 else ''),
             'stepper_path': ('direct 3x3 gathers' if args.direct else
                              ('f64 transition table' if (args.f64_table or args.exact_only)
                               else ('f32 ring table, exact fallback on the raw windows' if args.ring_table else
@@ -382,9 +496,15 @@ def main():
                                     'exact fallback on the raw windows'))),
             'potential': pot_label,
         },
+        # tracks/s depends on the terrain through the track lengths: the comparable figure is steps/s
         'steps_per_s': total_steps_all / elapsed,
-        'steps_per_track_mean': steps_per_track,
-        'steps_per_track_max': int(lengths.max() - 1),
+        'steps_per_track_mean': float(L.mean()),
+        'steps_per_track_median': float(np.median(L)),
+        'steps_per_track_max': int(L.max()),
+        'share_at_max_moves': float(np.mean(L >= max_moves)), 'max_moves': max_moves,
+        'launches_per_step': {'all': acc['launches'] // K, 'row_window': acc['window_launches'] // K,
+                              'tile_buckets': acc['tile_launches'] // K, 'block_windows': acc['block_window_launches'] // K,
+                              'wander_sorts': acc['wander_sorts'] // K},
         'raster_mcells_per_s': ncells / raster_s / 1e6 if raster_s > 0 else None,
         'raster_gbps': ncells * RASTER_BYTES_PER_CELL / raster_s / 1e9 if raster_s > 0 else None,
         'phase_ms_per_step': {
@@ -393,60 +513,60 @@ def main():
             'histogram_binning_k3': acc['hist_ms'] / K,
             'stepper_wall': acc['step_wall_ms'] / K,
         },
-        'roofline': {
-            'kernel': ('k_step_tracks' if (args.direct or args.f64_table or args.exact_only)
-                       else ('k_step_lean<ring>' if args.ring_table else 'k_step_thr')) + ' (K2 stepper, rank 0)',
-            # what bounds it: the dependent chain of one step (see dependent_chain below and
-            # profiles/r02_stepper_chain.md), not HBM: the kernel moves 8 B per step
-            'bound': 'latency',
-            # achieved = bytes the shipped data path really requests per step (the 4-byte
-            # threshold entry + the 4-byte visit) x steps / sum of the stepper launch durations
-            'achieved': moved_gbps, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-            'frac': moved_gbps / HBM_PEAK_GBPS,
-            'traffic': None,
-            'bytes_per_step': moved_bytes,
-            # launches of THIS kernel per bench step and their average duration (HIP events on the launch
-            # stream): the one-iteration first-move launch of the generic kernel is counted apart, so the
-            # average is the one rocprofv3 reports for the kernel (profiles/r02_final_kernel_stats.md)
-            'launches': main_launches // K,
-            'avg_launch_ms': main_kernel_ms / max(main_launches, 1),
-            'avg_bytes_per_launch': acc['steps'] * moved_bytes / max(main_launches, 1),
-            'first_move_launch_ms': acc.get('first_move_ms', 0.0) / K,
-            # SURVEY 8(d)'s 76 B/step is the gather volume of the REFERENCE's formulation (18 window
-            # reads + 1 point); the shipped path precomputes the windows into a table, so this
-            # figure can exceed the peak and is not a roofline fraction
-            'model_bytes_per_step': STEP_BYTES,
-            'model_gbps': achieved,
-            'model_frac': achieved / HBM_PEAK_GBPS,
-        },
+        'roofline': roof,
     }
-    # HBM bytes per launch from the PMC passes (profiles/, separate --pmc runs): only quoted when
-    # THIS run is the configuration those passes profiled
-    pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-    default_variant = (world == 1 and args.potential == 'ramp' and not (args.direct or args.f64_table or args.exact_only or args.ring_table
+    if solver:
+        out['solver'] = solver
+    default_variant = (world == 1 and not (args.direct or args.f64_table or args.exact_only or args.ring_table
                        or args.no_binning or args.no_schedule) and args.tracks == 100_000 and res == 10.0
                        and args.steps_per_launch in (0, 512) and args.dem_noise == 1.5)
-    if os.path.exists(pmc) and default_variant:
-        try:
-            with open(pmc) as f:
-                rec = json.load(f)
-            out['roofline']['traffic'] = rec.get('k_step_tracks_bytes_per_launch')
-            out['roofline']['traffic_source'] = ('profile constant (not counted in this run): '
-                                                 + str(rec.get('source')))
-        except Exception:
-            pass
+    attach_traffic(roof, default_variant)
     if world == 1 and not args.direct and not args.no_chain_probe:
-        out['roofline']['dependent_chain'] = chain_probe(args, movmodel, layers, dem, pot, starts_h, gridsize, res, seed)
-    if world == 1 and args.solved_tracks > 0 and args.potential != 'solve':
-        out['solved_potential'] = solved_leg(args, movmodel, layers, dem, starts_h, gridsize, res, seed)
+        roof['dependent_chain'] = chain_probe(args, movmodel, layers, dem, ramp, starts_h, gridsize, res, seed)
+    if world == 1 and solved and args.stand_in_steps > 0:
+        # the round-1/2 headline, kept so that the series survives: the same pass on the ramp
+        leg = Passes(args, mods, dem, ramp, starts, lo, gridsize, res, seed, world, dev)
+        el2, last2 = leg.run(args.stand_in_steps, 2)
+        k2 = args.stand_in_steps
+        roof2, _ = stepper_roofline(args, leg.acc, k2, False)
+        attach_traffic(roof2, default_variant)
+        l2 = last2.lengths.cpu().numpy().astype(np.int64) - 1
+        out['stand_in'] = {
+            'potential': ramp_label, 'steps': k2, 'warmup': 2,
+            'value': n_total * k2 / el2, 'unit': 'tracks/s', 'ms_per_step': el2 / k2 * 1e3,
+            'steps_per_s': leg.acc['steps'] / el2, 'steps_per_track_mean': float(l2.mean()),
+            'steps_per_track_max': int(l2.max()),
+            'phase_ms_per_step': {'raster_k1': leg.acc['raster_ms'] / k2, 'table_k2a': leg.acc['table_ms'] / k2,
+                                  'stepper_kernels_k2b': leg.acc['step_kernel_ms'] / k2,
+                                  'histogram_binning_k3': leg.acc['hist_ms'] / k2},
+            'roofline': roof2,
+            'what': 'the same pass on the linear-ramp stand-in potential (the headline of rounds 1-2): the batch crosses '
+                    'the raster as one front; after the timed region, not part of `value`',
+        }
     if world == 1 and args.cpu_seconds > 0:
-        cpu, run, m = cpu_baseline(args, gridsize, dem_h, pot.cpu().numpy(), starts_h, seed,
-                                   steps_per_track)
+        cap = args.cpu_cap if solved else None
+        _, upd_gpu = layers.updraft_from_dem(dem, res, 10.0, 270.0, threshold=0.75)
+        upd_gpu_h = upd_gpu.cpu().numpy()
+        cpu, run, m = cpu_baseline(args, gridsize, dem_h, upd_gpu_h, pot.cpu().numpy(), starts_h, seed, cap)
         out['cpu_baseline'] = cpu
-        # same tracks, same streams: the GPU's lengths for the sample must agree
-        # unless the usable-updraft rasters differ in the last f64 bits
-        out['cpu_baseline']['sample_lengths_equal_gpu'] = bool(
-            np.array_equal(run['lengths'], lengths[:m]))
+        # same tracks, same streams, same inputs, same cap: the GPU's lengths and histogram for the
+        # sample must be the oracle's, bit for bit
+        if cap:
+            sub = torch.from_numpy(starts_h[:m]).to(dev)
+            g = movmodel.simulate_tracks(0.0, sub, gridsize, 1, 1.0, upd_gpu, pot, seed=seed, max_moves=cap,
+                                         table=build_table(args, movmodel, upd_gpu, pot))
+            gl = g.lengths.cpu().numpy()
+            gh = g.hist.cpu().numpy().view(np.uint32)
+            cpu['sample_lengths_equal_gpu'] = bool(np.array_equal(run['lengths'], gl))
+            cpu['sample_histogram_equal_gpu'] = bool(np.array_equal(run['hist'], gh))
+            cpu['sample_share_at_cap'] = float(np.mean(gl - 1 >= cap))
+            cpu['sample_gpu_stats'] = {k: g.stats[k] for k in ('launches', 'block_window_launches', 'wander_sorts')}
+            # uncapped, the sample's tracks are the first m of the timed pass: those that finished under
+            # the cap have the same length there
+            done = run['lengths'] - 1 < cap
+            cpu['sample_finished_lengths_equal_timed_pass'] = bool(np.array_equal(run['lengths'][done], lengths[:m][done]))
+        else:
+            cpu['sample_lengths_equal_gpu'] = bool(np.array_equal(run['lengths'], lengths[:m]))
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

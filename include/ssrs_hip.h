@@ -198,6 +198,10 @@ typedef struct SsrsTrackStats {
     int32_t timed_launches;  /* stepper launches whose durations make up kernel_ms (PROFILE) */
     float first_move_ms;     /* of which: the one-iteration launch of the generic kernel that makes every
                                 track's first move before the threshold stepper takes over (PROFILE; else 0) */
+    float block_window_ms;   /* of which: the block-window launches (PROFILE; else 0) */
+    int32_t block_window_timed;   /* how many of them were timed */
+    int64_t block_window_steps;   /* moves taken in batches of block-window launches (from the per-batch
+                                     read-backs; a batch is one or two launches of one kind) */
 } SsrsTrackStats;
 
 /* Fills rows/cols/burnin/max_moves/memory/nu and zeroes the rest; `prior` must

@@ -277,13 +277,15 @@ def window_weights(row, col, updraft_field, potential_field, prior):
 def generate_simulated_tracks(move_dirn, start_location, grid_shape,
                               memory_parameter=1, scaling_parameter=1.,
                               updraft_field=None, potential_field=None,
-                              uniform=None):
+                              uniform=None, max_moves=None):
     """movmodel.py:264-318.  `uniform(step) -> u in [0,1)` supplies the one
     double per step that np.random.choice would draw; None = the legacy global
-    numpy stream (np.random.random_sample), i.e. the reference's own source."""
+    numpy stream (np.random.random_sample), i.e. the reference's own source.
+    `max_moves` (test / bench hook, like c_oracle's): a cap below the reference's R/2 * C/2."""
     num_rows, num_cols = grid_shape
     burnin = int(min(num_rows, num_cols) / 10)
-    max_moves = num_rows / 2 * num_cols / 2
+    if max_moves is None:
+        max_moves = num_rows / 2 * num_cols / 2
     prior = [float(v) for v in get_directional_probs(move_dirn * np.pi / 180.)]
     masks = {d: get_track_restrictions(*d) for d in NEIGHBOUR_DELTAS}
     directions = [(0, 0)]

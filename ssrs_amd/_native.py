@@ -52,7 +52,9 @@ class SsrsTrackStats(C.Structure):
                 ('kernel_ms', C.c_float), ('wall_ms', C.c_float), ('hist_ms', C.c_float),
                 ('window_launches', C.c_int32), ('tile_launches', C.c_int32),
                 ('block_window_launches', C.c_int32), ('wander_sorts', C.c_int32),
-                ('timed_launches', C.c_int32), ('first_move_ms', C.c_float)]
+                ('timed_launches', C.c_int32), ('first_move_ms', C.c_float),
+                ('block_window_ms', C.c_float), ('block_window_timed', C.c_int32),
+                ('block_window_steps', C.c_int64)]
 
 
 class SsrsSolveStats(C.Structure):

@@ -3260,6 +3260,8 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
     constexpr int kSlotWords = 40;           // 160 bytes of TrackCtl: counts .. strays
     static_assert(offsetof(TrackCtl, strays) + sizeof(unsigned long long) <= kSlotWords * sizeof(uint32_t), "read-back slot");
     int slot_row[kRing] = {};
+    bool slot_block_window[kRing] = {};      // the batch's launches counted in block windows
+    long long block_window_steps = 0;
     const bool direct_read_back = std::getenv("SSRS_TRACKS_COPY_READ_BACK") == nullptr;      // A/B switch
     // (profile mode: every batch gets its own event, which is also the start mark of the next launch)
     hipEvent_t ev_batch[kRing] = {};
@@ -3340,6 +3342,7 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
         const int depth = (thr && last_Sl >= 512 && launch < 24) ? 1 : kBatch;
         const int slot = batches % kRing;
         bool read_back_done = false;             // the batch's last binning kernel wrote the slot itself
+        bool batch_block_window = false;
         for (int j = 0; j < depth; ++j, ++launch) {
             a.launch = launch;
             a.list_in = (launch == 0 && !coherent) ? nullptr : ws.list[launch & 1];
@@ -3431,6 +3434,7 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                 }
             }
             if (profile && !marks_adjacent) mark(0);
+            bool is_block_window = false;
             // 16-bit visit keys: north-bound front through the row window, nothing recorded
             // (the stepper forms the key base (first start row + iteration - 1) * cols in 32 bits)
             const bool v16 = thr && bin_window && a.visits == ws.visits && a.pf_dir == 1 && !hist_t && v16_ok &&
@@ -3449,6 +3453,7 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                     const bool rev = thr_prior.rev_ok != 0 && std::getenv("SSRS_TRACKS_NO_REV") == nullptr;
                     if (cached && !a.visits) {
                         ++block_window_launches;
+                        batch_block_window = is_block_window = true;
                         if (rev) hipLaunchKernelGGL((k_step_thr<6, false, true>), dim3(blocks), dim3(kBlock), 0, st, a, thr_prior);
                         else hipLaunchKernelGGL((k_step_thr<6>), dim3(blocks), dim3(kBlock), 0, st, a, thr_prior);
                         break;
@@ -3478,7 +3483,7 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
             case MODE_UPDRAFT: hipLaunchKernelGGL(k_step_tracks<MODE_UPDRAFT>, dim3(blocks), dim3(kBlock), 0, st, a); break;
             default: hipLaunchKernelGGL(k_step_tracks<MODE_PRIOR>, dim3(blocks), dim3(kBlock), 0, st, a); break;
             }
-            if (profile) mark(1);      // end of the stepper launch
+            if (profile) mark(is_block_window ? 3 : 1);      // end of the stepper launch
             if (bin_window) {
                 ++window_launches;
                 if (v16) {
@@ -3548,6 +3553,7 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
             break;
         }
         slot_row[slot] = launch & 3;
+        slot_block_window[slot] = batch_block_window;
         ++batches;
         // examine every batch but the one just queued (it keeps the GPU busy)
         while (checked < batches - 1) {
@@ -3559,6 +3565,7 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
             unsigned long long tot[2];
             memcpy(tot, &host_counts[kSlotWords * cs + offsetof(TrackCtl, steps) / sizeof(uint32_t)], sizeof(tot));
             ++checked;
+            if (slot_block_window[cs]) block_window_steps += static_cast<long long>(tot[0] - seen_steps);
             if (c == 0) { finished = true; break; }
             // the live count only shrinks, a stale bound is safe -- except across a wander sort
             upper = (checked - 1 >= upper_from || c > upper) ? c : upper;
@@ -3662,6 +3669,8 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
         stats->tile_launches = tile_launches;
         stats->block_window_launches = block_window_launches;
         stats->wander_sorts = wander_sorts;
+        // (batches still unexamined when the loop ended: the last one or two of the run)
+        stats->block_window_steps = block_window_steps;
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, ev_first, ev_last) == hipSuccess) stats->wall_ms = ms;
         if (profile) {
@@ -3669,10 +3678,11 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
             int timed = 0;
             for (size_t i = 1; i < ev_marks.size(); ++i) {
                 if (mark_kind[i] == 0 || hipEventElapsedTime(&ms, ev_marks[i - 1], ev_marks[i]) != hipSuccess) continue;
-                if (mark_kind[i] == 1) {
+                if (mark_kind[i] == 1 || mark_kind[i] == 3) {
                     sum += ms;
                     if (timed == 0 && thr) stats->first_move_ms = ms;      // (launch 0 of a threshold-table call)
                     ++timed;
+                    if (mark_kind[i] == 3) { stats->block_window_ms += ms; ++stats->block_window_timed; }
                 } else {
                     hsum += ms;
                 }

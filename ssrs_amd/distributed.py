@@ -43,7 +43,8 @@ def reduce_presence_sum(summary, group=None):
 
 
 class HistogramOverflow(OverflowError):
-    """The sum of the ranks' per-cell maxima reaches 2^32: a 32-bit reduce could wrap."""
+    """A uint32 presence count may have wrapped (single-rank guard of Simulator.simulate_tracks;
+    the multi-rank reduce widens instead of raising)."""
 
 
 def _max_bound(hist, group):
@@ -63,19 +64,15 @@ def _local_max(flat):
 
 
 class _GuardedWork:
-    """Handle of an asynchronous guarded reduce: wait() orders the stream after the
-    collective and raises HistogramOverflow when the 32-bit sum may have wrapped."""
+    """Handle of an asynchronous guarded reduce: wait() orders the current stream after the
+    collective; `result` is the tensor that holds the sum (the caller's `hist`, or its int64
+    widening when a 32-bit sum could have wrapped)."""
 
-    def __init__(self, work, bound_work, bound):
-        self._work, self._bound_work, self._bound = work, bound_work, bound
+    def __init__(self, work, result):
+        self._work, self.result = work, result
 
     def wait(self):
         self._work.wait()
-        if self._bound_work is not None:
-            self._bound_work.wait()
-            if int(self._bound.item()) >= (1 << 32):
-                raise HistogramOverflow('presence histogram: a cell may exceed 2^32 - 1 visits over '
-                                        'the ranks; reduce with async_op=False (64-bit sum)')
         return True
 
 
@@ -92,12 +89,13 @@ def reduce_histogram(hist, dst=0, group=None, all_ranks=False, async_op=False, g
     per 100k tracks, so eight such ranks would wrap a 32-bit sum.  No-op without a
     process group.
 
-    async_op=True returns a handle (or None when there is nothing to reduce) whose
-    ``wait()`` orders the current stream after the collective: the reduce of one
-    batch's histogram then runs on RCCL's stream under the next batch's stepper
-    launches (the caller must not touch `hist` before ``wait()``).  The asynchronous
-    form always reduces 32-bit counts in place; its guard raises HistogramOverflow from
-    ``wait()`` instead of widening."""
+    async_op=True returns a handle (or None when there is nothing to reduce): the bound is
+    agreed on first (one scalar all-reduce and a host read, microseconds), then the 32-bit sum
+    in place or the widened 64-bit sum is queued on the collective's stream and runs under the
+    next batch's stepper launches; ``wait()`` orders the current stream after it and
+    ``handle.result`` is the tensor that holds the sum (the caller must not touch `hist`
+    before ``wait()``).  Round 2's asynchronous form raised HistogramOverflow from ``wait()``
+    instead of widening, which aborted an 8-GPU run on the solved field by design."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return None if async_op else hist
     flat = hist.view(torch.int32).reshape(-1)
@@ -107,14 +105,14 @@ def reduce_histogram(hist, dst=0, group=None, all_ranks=False, async_op=False, g
             return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, **kw)
         return dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM, group=group, **kw)
 
-    if async_op:
-        bound = bound_work = None
-        if guard:
-            bound = _local_max(flat)
-            bound_work = dist.all_reduce(bound, op=dist.ReduceOp.SUM, group=group, async_op=True)
-        return _GuardedWork(run(flat, async_op=True), bound_work, bound)
+    wide = None
     if guard and int(_max_bound(hist, group).item()) >= (1 << 32):
         wide = flat.to(torch.int64) & 0xFFFFFFFF
+    if async_op:
+        if wide is not None:
+            return _GuardedWork(run(wide, async_op=True), wide.reshape(hist.shape))
+        return _GuardedWork(run(flat, async_op=True), hist)
+    if wide is not None:
         run(wide)
         return wide.reshape(hist.shape)
     run(flat)

@@ -341,7 +341,10 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
                            tile_launches=int(stats.tile_launches),
                            block_window_launches=int(stats.block_window_launches),
                            wander_sorts=int(stats.wander_sorts), timed_launches=int(stats.timed_launches),
-                           first_move_ms=float(stats.first_move_ms), recorded=bool(recorded)))
+                           first_move_ms=float(stats.first_move_ms), recorded=bool(recorded),
+                           block_window_ms=float(stats.block_window_ms),
+                           block_window_timed=int(stats.block_window_timed),
+                           block_window_steps=int(stats.block_window_steps)))
 
 
 def generate_simulated_tracks(move_dirn, start_location, grid_shape, memory_parameter=1,

@@ -1,0 +1,92 @@
+"""The roaming path at its real size: BASELINE configs[1] -- 5000 x 6000 @10 m, the
+build's own K5 potential -- where 44 % of a batch reaches a basin of the field and circles there
+until max_moves (/root/reference/ssrs/movmodel.py:285-317: `while k < max_moves` with the exit test
+only at the raster's edge).  That regime runs in the block-window launches (the wander sort, windows
+chosen from the data, tombstoned lists); until this file its parity tests ran on synthetic Gaussian
+wells at 700 x 1100.  Here: 20 000 tracks against the C oracle on the SAME rasters with max_moves
+capped on both sides (the oracle does 4-5e8 steps in seconds on the box's host threads), and an
+uncapped batch checked through what needs no oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+SHAPE, RES = (5000, 6000), 10.
+CAP = 60_000
+
+
+@pytest.fixture(scope='module')
+def c2_field(gpu):
+    """DEM -> K1 -> usable updraft -> K5 potential at the default tolerance, on the device and on the host."""
+    from ssrs_amd import layers, movmodel
+    from ssrs_amd.potential import solve_potential
+    from ssrs_amd.synthetic import synthetic_dem
+    dem = torch.from_numpy(synthetic_dem(SHAPE, RES)).cuda()
+    _, upd = layers.updraft_from_dem(dem, RES, 10., 270., threshold=0.75)
+    del dem
+    pot, st = solve_potential(upd, 0., return_stats=True)
+    assert st['converged'], st
+    np.random.seed(30)
+    r, c = movmodel.get_starting_indices(100_000, (5, 55, 1, 2), 'random', (60., 50.), RES)
+    starts = np.stack([r, c], 1).astype(np.int32)
+    return dict(upd=upd, pot=pot, upd_h=upd.cpu().numpy(), pot_h=pot.cpu().numpy(), starts=starts, shared={})
+
+
+def test_roaming_batch_vs_oracle_at_c2(c2_field):
+    from ssrs_amd import movmodel
+    from oracle import c_oracle
+    f = c2_field
+    n = 20_000
+    starts = f['starts'][:n]
+    ref = c_oracle.simulate_tracks(0., starts, SHAPE, 1, 1., f['upd_h'], f['pot_h'], seed=30, want_traj=False,
+                                   max_moves=CAP)
+    got = movmodel.simulate_tracks(0., starts, SHAPE, 1, 1., f['upd'], f['pot'], seed=30, max_moves=CAP)
+    st = got.stats
+    # the batch really went through the roaming machinery
+    assert st['block_window_launches'] > 0 and st['wander_sorts'] > 0, st
+    lengths = got.lengths.cpu().numpy()
+    assert np.array_equal(lengths, ref['lengths'])
+    assert np.array_equal(got.ends.cpu().numpy(), ref['ends'])
+    hist = got.hist.cpu().numpy().view(np.uint32)
+    assert np.array_equal(hist, ref['hist'])
+    assert int(hist.sum(dtype=np.uint64)) == st['total_steps'] + n == ref['steps'] + n
+    at_cap = float(np.mean(lengths - 1 >= CAP))
+    assert 0.25 < at_cap < 0.6, at_cap          # the basins hold 30-45 % of a batch on this field
+    f['shared']['survivors'] = at_cap
+    # the same batch through the tile buckets only (A/B switch of the block windows): same integers
+    import os
+    os.environ['SSRS_TRACKS_NO_BLOCK_WINDOW'] = '1'
+    try:
+        alt = movmodel.simulate_tracks(0., starts, SHAPE, 1, 1., f['upd'], f['pot'], seed=30, max_moves=CAP)
+    finally:
+        del os.environ['SSRS_TRACKS_NO_BLOCK_WINDOW']
+    assert alt.stats['block_window_launches'] == 0
+    assert torch.equal(alt.lengths, got.lengths) and torch.equal(alt.hist, got.hist)
+
+
+def test_uncapped_batch_properties_at_c2(c2_field):
+    """No oracle can follow 7.5e6 moves per track; what holds without one: the histogram counts every
+    point once, tracks end on the raster's edge or at max_moves exactly, and the share that wanders to
+    max_moves is the capped run's share of survivors (a track alive after 60 000 moves sits in a basin)."""
+    from ssrs_amd import movmodel
+    f = c2_field
+    n = 2_000
+    starts = f['starts'][:n]
+    got = movmodel.simulate_tracks(0., starts, SHAPE, 1, 1., f['upd'], f['pot'], seed=30)
+    lengths = got.lengths.cpu().numpy().astype(np.int64)
+    ends = got.ends.cpu().numpy()
+    mm = SHAPE[0] // 2 * (SHAPE[1] // 2)
+    hist = got.hist.cpu().numpy().view(np.uint32)
+    assert int(hist.sum(dtype=np.uint64)) == got.stats['total_steps'] + n == int((lengths - 1).sum()) + n
+    assert lengths.max() == mm + 1
+    on_edge = (ends[:, 0] == 0) | (ends[:, 0] == SHAPE[0] - 1) | (ends[:, 1] == 0) | (ends[:, 1] == SHAPE[1] - 1)
+    assert np.all(on_edge | (lengths == mm + 1))
+    share = float(np.mean(lengths == mm + 1))
+    # the first 2 000 tracks of the capped batch are these very tracks
+    capped = movmodel.simulate_tracks(0., starts, SHAPE, 1, 1., f['upd'], f['pot'], seed=30, max_moves=CAP)
+    cl = capped.lengths.cpu().numpy().astype(np.int64)
+    survivors = float(np.mean(cl - 1 >= CAP))
+    assert abs(share - survivors) <= 0.05, (share, survivors)
+    # and every track that finished under the cap has the same length uncapped
+    done = cl - 1 < CAP
+    assert np.array_equal(cl[done], lengths[done])
