@@ -66,8 +66,10 @@ def test_roaming_batch_vs_oracle_at_c2(c2_field):
 
 def test_uncapped_batch_properties_at_c2(c2_field):
     """No oracle can follow 7.5e6 moves per track; what holds without one: the histogram counts every
-    point once, tracks end on the raster's edge or at max_moves exactly, and the share that wanders to
-    max_moves is the capped run's share of survivors (a track alive after 60 000 moves sits in a basin)."""
+    point once, tracks end on the raster's edge or at max_moves exactly, every track that finished under
+    the cap has the same length uncapped, and the share that wanders to max_moves is bounded by the
+    capped run's share of survivors (measured here: 44 % alive after 60 000 moves, 30 % at max_moves --
+    a third of the tracks in the basins find a way out within 7.5e6 moves)."""
     from ssrs_amd import movmodel
     f = c2_field
     n = 2_000
@@ -86,7 +88,7 @@ def test_uncapped_batch_properties_at_c2(c2_field):
     capped = movmodel.simulate_tracks(0., starts, SHAPE, 1, 1., f['upd'], f['pot'], seed=30, max_moves=CAP)
     cl = capped.lengths.cpu().numpy().astype(np.int64)
     survivors = float(np.mean(cl - 1 >= CAP))
-    assert abs(share - survivors) <= 0.05, (share, survivors)
+    assert 0.2 < share <= survivors < 0.6, (share, survivors)
     # and every track that finished under the cap has the same length uncapped
     done = cl - 1 < CAP
     assert np.array_equal(cl[done], lengths[done])
