@@ -202,6 +202,12 @@ typedef struct SsrsTrackStats {
     int32_t block_window_timed;   /* how many of them were timed */
     int64_t block_window_steps;   /* moves taken in batches of block-window launches (from the per-batch
                                      read-backs; a batch is one or two launches of one kind) */
+    int32_t roam_launches;        /* block-window launches that stepped through the windows' roam table
+                                     (two moves per 64-byte entry, k_step_roam) */
+    int32_t reserved0;
+    int64_t roam_wave_pairs;      /* pairs of moves run by the waves of those launches ... */
+    int64_t roam_slow_wave_pairs; /* ... and how many of them sent some lane through the single-move sequence
+                                     (near-ties, flag entries, moves out of the window, burn-in) */
 } SsrsTrackStats;
 
 /* Fills rows/cols/burnin/max_moves/memory/nu and zeroes the rest; `prior` must
@@ -255,7 +261,10 @@ int ssrs_transition_thr_build(const double *updraft, const float *potential, con
  * windows of 144 x 256 cells and counted in LDS (SsrsTrackStats.block_window_launches);
  * nothing to size for it. */
 size_t ssrs_tracks_workspace_bytes(int64_t ntracks);
-/* The same plus room for `hist_copies` (2..64) private copies of the histogram.  A
+/* The same plus (i) the pair table of the roaming regime -- 128 bytes per cell (3.84 GB at 5000 x 6000),
+ * batches of >= 8192 tracks on rasters below 2^25 cells: with it the block-window launches take two moves
+ * per 16-byte gather (SsrsTrackStats.roam_launches), without it they run round 2's one-gather-per-move
+ * kernel, 2.1x slower -- and (ii) room for `hist_copies` (2..64) private copies of the histogram.  A
  * workspace of this size lets ssrs_tracks_simulate privatise the histogram once a batch
  * is scattered (many tracks circling in the same pockets of a real potential field make
  * per-step atomics on single cells queue up at the memory side: 3x slower); the copies

@@ -565,7 +565,9 @@ struct alignas(16) TrackCtl {
     uint32_t bin_done;           // blocks of the running k_bin_visits16 that have finished (read-back by the last)
     uint32_t pad;
     double prior[9];             // directional prior of this call (read by the slow paths)
-    double pad2;
+    unsigned long long roam_slow;   // k_step_roam: wave-pairs in which some lane took the slow path
+    unsigned long long roam_pairs;  // k_step_roam: wave-pairs run
+    unsigned long long dbg_tsum, dbg_tmax, dbg_waves, dbg_slowmax;   // SSRS_TRACKS_DEBUG_ROAM: wave lifetimes of one launch
 };
 
 static_assert(sizeof(TrackCtl) <= 128 * sizeof(uint32_t), "final read-back slot of pinned_counts()");
@@ -573,6 +575,8 @@ static_assert(sizeof(TrackCtl) <= 128 * sizeof(uint32_t), "final read-back slot 
 // block histogram windows of wandering batches (k_step_thr<6>, k_wander_windows)
 constexpr int kWinRows = 144, kWinCols = 256;      // 144 KB of LDS: one block per CU
 constexpr int kWanderWindows = 16;
+constexpr uint32_t kDealBlocks = 232;              // blocks the contiguous deal spreads the live tracks over (+ one per
+                                                   // window in use and the padding: under the 256 CUs)
 constexpr int kBinRows = kWinRows / 4, kBinCols = kWinCols / 4;
 constexpr int kWanderBins = 16384;           // 64 KB of LDS
 struct WanderWindows {
@@ -645,6 +649,8 @@ __device__ __forceinline__ int wander_window_of(const WanderWindows *__restrict_
 
 enum { MODE_PRIOR = 0, MODE_UPDRAFT = 1, MODE_FLUIDFLOW = 2, MODE_TABLE = 3 };
 
+struct RoamEntry;
+
 struct StepArgs {
     int rows, cols, burnin, memory;
     long long max_k;
@@ -683,6 +689,8 @@ struct StepArgs {
     uint32_t *hist_copies;       // privatised histogram copies (scattered batches), or NULL
     int ncopies;
     const WanderWindows *wander; // k_step_thr<6>: the windows of the last wander sort (n = 0: none yet)
+    const RoamEntry *roam;       // k_step_roam: the pair table (8 entries per cell of the raster), or NULL
+    int debug_roam;              // k_step_roam: wave lifetimes into the control block (SSRS_TRACKS_DEBUG_ROAM)
     uint32_t vis_r, vis_c;       // visit key = row * vis_r + col * vis_c: (cols, 1), or (1, rows) when
                                  // the front is a column (east / west headings: transposed binning)
 };
@@ -981,7 +989,8 @@ __global__ void k_ctl_init(TrackCtl *ctl, const PriorArg pr, double *__restrict_
             bad = (header->magic != kThrMagic || header->rows != rows || header->cols != cols) ? 2u : 0u;
             for (int k = 0; k < 9; ++k) bad |= (header->prior[k] != pr.v[k]) ? 2u : 0u;
         }
-        ctl->error = bad; ctl->par_min = 0xFFFFFFFFu; ctl->steps = 0; ctl->strays = 0; ctl->bin_done = 0; ctl->pad = 0; ctl->pad2 = 0.0;
+        ctl->error = bad; ctl->par_min = 0xFFFFFFFFu; ctl->steps = 0; ctl->strays = 0; ctl->bin_done = 0; ctl->pad = 0; ctl->roam_slow = 0; ctl->roam_pairs = 0;
+        ctl->dbg_tsum = ctl->dbg_tmax = ctl->dbg_waves = ctl->dbg_slowmax = 0;
     }
     if (d < 9) ctl->prior[d] = pr.v[d];
     if (d >= 9) return;
@@ -2034,6 +2043,375 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
     if (lane == 0 && mv) atomicAdd(&ctl->steps, mv);
 }
 
+// ------------------------------------------------------------ pair table (round 3)
+// What a roaming batch costs: on the solved 10 m field 44 % of a batch circles in two basins until
+// max_moves = 7.5e6, every lane of a wave somewhere else in its basin, and a step of k_step_thr<6> is one
+// fully divergent 4-byte gather.  The CU's address unit takes ~4 clocks per lane of such a load
+// (tools/microbench/gather.hip: ~7 per distinct line; 256 lanes per CU -> the measured 1030 clocks per
+// iteration) whatever the latency: the round-2 notes called the regime latency-bound; the first version
+// of this table (64-byte entries with successor indices, four loads per pair of moves) ran 1.8x SLOWER
+// although it halved the instructions and took the decode off the chain, which settled it
+// (profiles/r03_notes.md).  So the table serves one thing: fewer divergent loads per move.
+//   * a state is (cell, last move); its 16-byte entry holds the thresholds of the state AND of the three
+//     cells its move can lead to, so ONE dwordx4 load decides a PAIR of moves (one Philox block = two
+//     uniforms); the 8 states of a cell are one 128-byte line;
+//   * the table covers the whole raster (128 bytes per cell, 3.84 GB at 5000 x 6000, built in ~2 ms when
+//     a batch starts to roam): a first version with a slab per wander window lost 2-3x to the ONE wave
+//     per launch that had a lane outside its slab -- a launch lasts as long as its slowest wave.
+// Everything irregular stays out of the fast path: a flag entry, a near-tie, the burn-in, a pair cut
+// short by max_moves or by the release schedule sends the lane through `slow_step`, the single-move
+// sequence of k_step_thr on the plain threshold table (and from there, where needed, through the
+// reference's exact sequence on the raw windows), after which the lane looks its state up again.
+// Decisions are the same integers compared with the same thresholds as in k_step_thr, so the results
+// are identical (same tests; SSRS_TRACKS_NO_ROAM_TABLE is the A/B switch).
+struct alignas(16) RoamEntry {
+    uint32_t e0, ea, eb, ec;     // raw threshold entries of the state and of the cells its move leads to
+                                 // (a: u < T1, b: u < T2, c: else; after the reversal substitution of e0)
+};
+static_assert(sizeof(RoamEntry) == 16, "one dwordx4 per state");
+constexpr size_t kPairMaxCells = 1ull << 25;       // 32-bit byte offsets: 128 bytes per cell
+
+template <bool REV>
+__global__ __launch_bounds__(kBlock) void k_roam_build(const char *__restrict__ tab, uint32_t guard, int plane_shift,
+                                                      int rows, int cols, RoamEntry *__restrict__ out, const ThrPrior pr)
+{
+    // one thread per state; a block covers 32 consecutive cells x 8 last moves, the grid walks the raster
+    const uint32_t nstate = static_cast<uint32_t>(rows) * static_cast<uint32_t>(cols) * 8u;
+    for (uint32_t s = blockIdx.x * kBlock + threadIdx.x; s < nstate; s += gridDim.x * kBlock) {
+        const uint32_t rc = s & 7u, cell = s >> 3;
+        auto entry = [&](uint32_t c, uint32_t q) {
+            return *reinterpret_cast<const uint32_t *>(tab + (guard + (q << plane_shift)) + (c << 2));
+        };
+        uint4 en = make_uint4(entry(cell, rc), kThrPoison, kThrPoison, kThrPoison);
+        const bool rev = REV && en.x == kThrReversal;
+        const uint32_t eu = rev ? pr.rev_e : en.x, rcd = rev ? pr.rev_rc : rc;
+        if ((eu & 0xFFFFu) <= (eu >> 16)) {
+            // (a row that is no flag belongs to an interior cell: its neighbours are cells of the raster)
+            const uint32_t ord = static_cast<uint32_t>(kRingOrder >> (6u * rcd)) & 63u;
+            uint32_t es[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const uint32_t ncj = (rcd + 7u + ((ord >> (2 * j)) & 3u)) & 7u;
+                const uint32_t cj = cell + ((kRingDr >> (2u * ncj)) & 3u) * static_cast<uint32_t>(cols) + ((kRingDc >> (2u * ncj)) & 3u) -
+                                    static_cast<uint32_t>(cols) - 1u;
+                es[j] = entry(cj, ncj);
+            }
+            en.y = es[0]; en.z = es[1]; en.w = es[2];
+        }
+        reinterpret_cast<uint4 *>(out)[s] = en;
+    }
+}
+
+template <bool REV>
+__global__ __launch_bounds__(kBlock) void k_step_roam(const StepArgs a, const ThrPrior pr)
+{
+    __shared__ uint32_t s_win[kWinRows * kWinCols];
+    __shared__ int s_box[4];
+    __shared__ int s_wid[kBlock / 64];
+    for (int q = threadIdx.x; q < kWinRows * kWinCols; q += kBlock) s_win[q] = 0u;
+    if (threadIdx.x == 0) { s_box[0] = s_box[1] = 0x7fffffff; s_box[2] = s_box[3] = -1; }
+    __syncthreads();
+    TrackCtl *ctl = a.ctl;
+    const int in_slot = a.launch & 3, out_slot = (a.launch + 1) & 3;
+    const uint32_t xcd = blockIdx.x % kXcd;
+    const uint32_t nlive = ctl->count[in_slot][xcd];
+    const uint32_t il = (blockIdx.x / kXcd) * kBlock + threadIdx.x;
+    const uint32_t i = xcd * a.cap + il;
+    if (blockIdx.x == 0 && threadIdx.x < kXcd) ctl->count[(a.launch + 2) & 3][threadIdx.x] = 0;
+
+    bool live0 = il < nlive;
+    int32_t t = live0 ? (a.list_in ? a.list_in[i] : static_cast<int32_t>(i)) : 0;
+    if (t < 0) { live0 = false; t = 0; }                  // tombstone
+    TrackState s = {0, -1, 0, 0};
+    if (live0) s = a.state[t];
+    uint32_t rc = static_cast<uint32_t>(kRingOfK >> (4 * (s.dirs & 0xFu))) & 0xFu;
+    live0 = live0 && s.k >= 0 && rc < 8u;                 // (every track has made its first move)
+    rc &= 7u;
+    int row = s.pos & 0xFFFF, col = (s.pos >> 16) & 0xFFFF;
+    // the block's histogram window: as in k_step_thr<6> (the window the sort filled this block from; the
+    // bounding box of its tracks otherwise)
+    int win_r0 = 0, win_c0 = 0;
+    {
+        int r_lo = live0 ? row : 0x7fffffff, r_hi = live0 ? row : -1, c_lo = live0 ? col : 0x7fffffff, c_hi = live0 ? col : -1;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            int o = __shfl_xor(r_lo, off); r_lo = o < r_lo ? o : r_lo;
+            o = __shfl_xor(r_hi, off); r_hi = o > r_hi ? o : r_hi;
+            o = __shfl_xor(c_lo, off); c_lo = o < c_lo ? o : c_lo;
+            o = __shfl_xor(c_hi, off); c_hi = o > c_hi ? o : c_hi;
+        }
+        if ((threadIdx.x & 63) == 0 && r_hi >= 0) {
+            atomicMin(&s_box[0], r_lo); atomicMin(&s_box[1], c_lo);
+            atomicMax(&s_box[2], r_hi); atomicMax(&s_box[3], c_hi);
+        }
+        __syncthreads();
+        const bool fits = s_box[2] - s_box[0] < kWinRows && s_box[3] - s_box[1] < kWinCols;
+        const int nwin = a.wander->n;
+        int wid = live0 && nwin > 0 ? wander_window_of(a.wander, nwin, row, col) : 0x7fffffff;
+        wid = wid >= nwin ? 0x7fffffff : wid;
+        {
+            const unsigned long long lm = __ballot(wid != 0x7fffffff);
+            wid = lm ? __shfl(wid, __ffsll(static_cast<long long>(lm)) - 1) : 0x7fffffff;
+        }
+        if ((threadIdx.x & 63) == 0) s_wid[threadIdx.x >> 6] = wid;
+        __syncthreads();
+        wid = 0x7fffffff;
+        for (int q = kBlock / 64 - 1; q >= 0; --q) wid = s_wid[q] != 0x7fffffff ? s_wid[q] : wid;
+        if (wid != 0x7fffffff && threadIdx.x == 0) {
+            s_box[0] = a.wander->r0[wid]; s_box[2] = s_box[0] + kWinRows - 1;
+            s_box[1] = a.wander->c0[wid]; s_box[3] = s_box[1] + kWinCols - 1;
+        }
+        const bool placed = wid != 0x7fffffff;
+        __syncthreads();
+        if (!placed && !fits && threadIdx.x == 0) { s_box[0] = r_lo; s_box[1] = c_lo; s_box[2] = r_hi; s_box[3] = c_hi; }
+        __syncthreads();
+        if (s_box[2] >= 0) {
+            win_r0 = (s_box[0] + s_box[2] + 1 - kWinRows) / 2;
+            win_c0 = (s_box[1] + s_box[3] + 1 - kWinCols) / 2;
+        }
+    }
+    const char *pair = reinterpret_cast<const char *>(a.roam);
+    const uint32_t ucols = static_cast<uint32_t>(a.cols);
+    const int win_cell0 = win_r0 * a.cols + win_c0;       // linear index of the window's origin (may be negative)
+    const uint32_t last_cell = static_cast<uint32_t>(a.rows) * ucols - 1u;
+    int k = s.k;
+    // iterations [it_base, it_base + steps) of the batch; a lane steps while rel <= it < rel + span
+    // (see k_step_thr: rel is odd or 0, k - rel is even, one Philox block per even / odd pair)
+    const long long rel64 = (a.coherent ? static_cast<long long>(s.aux >> 9) : 0) + 1 - a.it_base;
+    const int rel = rel64 > 0x3fffffffLL ? 0x3fffffff : (rel64 < 0 ? 0 : static_cast<int>(rel64));
+    const long long left = a.max_k - k;
+    uint32_t span = !live0 ? 0u : (left > 0x3fffffffLL ? 0x3fffffffu : (left < 0 ? 0u : static_cast<uint32_t>(left)));
+    const int blk0 = (k - rel) >> 1;
+    const unsigned long long track = a.track_base + static_cast<unsigned long long>(t);
+    const char *tab = reinterpret_cast<const char *>(a.table);
+    const uint32_t psh = static_cast<uint32_t>(a.plane_shift);
+    const uint32_t rev_e = pr.rev_e, rev_rc = pr.rev_rc;
+    uint32_t win_stray = 0;
+
+    // ---- the lane's place: window coordinates (wr, wc) -- any integers, the cell is win_cell0 + wr cols + wc --
+    // and the entry of its state.  `fast`: released and beyond its burn-in
+    int wr = 0, wc = 0;
+    bool fast = false;
+    uint4 E = make_uint4(kThrPoison, kThrPoison, kThrPoison, kThrPoison);
+    auto enter = [&](bool released) __attribute__((always_inline)) {
+        wr = row - win_r0;
+        wc = col - win_c0;
+        fast = live0 && released && span != 0u && k > a.burnin;
+        const uint32_t sidx = fast ? (((static_cast<uint32_t>(row) * ucols + static_cast<uint32_t>(col)) << 3) | rc) : 0u;
+        E = *reinterpret_cast<const uint4 *>(pair + (sidx << 4));
+    };
+    enter(rel == 0);
+
+    // ---- one move by the rules of k_step_thr's special branch, written plainly (rare: ~1 % of the pairs)
+    auto slow_step = [&](const uint32_t w0, const uint32_t w1) __attribute__((always_inline)) {
+        const uint32_t ufi = w0 >> 16;
+        const uint32_t cell = static_cast<uint32_t>(row) * ucols + static_cast<uint32_t>(col);
+        const uint32_t e = *reinterpret_cast<const uint32_t *>(tab + (a.guard + (rc << psh)) + (cell << 2));
+        const int32_t d1 = static_cast<int32_t>(ufi) - static_cast<int32_t>(e & 0xFFFFu);
+        const int32_t d2 = static_cast<int32_t>(ufi) - static_cast<int32_t>(e >> 16);
+        const bool burn = k <= a.burnin;
+        bool special = (static_cast<uint32_t>(d1 + 1) < 2u) | (static_cast<uint32_t>(d2 + 1) < 2u) | (d1 < d2);
+        if (burn) special |= (row <= 1) | (row >= a.rows - 2) | (col >= a.cols - 2);
+        uint32_t nc;
+        int br = row, bc = col;
+        if (!special) {
+            const uint32_t ord = static_cast<uint32_t>(kRingOrder >> (6u * rc)) & 63u;
+            const uint32_t neg = (static_cast<uint32_t>(d1) >> 31) + (static_cast<uint32_t>(d2) >> 31);
+            nc = (rc + 7u + ((ord >> (4u - 2u * neg)) & 3u)) & 7u;
+        } else {
+            if (e == kThrBoundary && !burn) { span = 0u; return; }      // movmodel.py:286-288: the track ends here
+            bool exact = true;
+            nc = 0;
+            if (e == kThrReversal && !burn) {
+                // unmasked prior (movmodel.py:239-240): count of thresholds <= u
+                int idx = 0;
+                bool near = false;
+#pragma unroll
+                for (int q = 0; q < 9; ++q) {
+                    const int32_t d = static_cast<int32_t>(ufi) - static_cast<int32_t>(pr.thr9[q]);
+                    idx += d >= 0 ? 1 : 0;
+                    near |= static_cast<uint32_t>(d + 1) < 2u;
+                }
+                const uint32_t pnc = static_cast<uint32_t>(kRingOfK >> (4 * (idx > 8 ? 4 : idx))) & 0xFu;
+                if (!near && pnc < 8u) { nc = pnc; exact = false; }
+            }
+            if (exact) {
+                // near-ties, poisoned rows, the burn-in nudge: the reference's exact sequence on the raw
+                // windows (movmodel.py:285-312)
+                int er = row, ec = col;
+                if (burn) {
+                    if (er <= 1) er += 2; else if (er >= a.rows - 2) er -= 2;
+                    if (ec <= 0) ec += 2; else if (ec >= a.cols - 2) ec -= 2;
+                }
+                double w[9];
+                if (a.potential) window_weights<true>(a.updraft, a.potential, a.cols, er, ec, w);
+                else window_weights<false>(a.updraft, a.potential, a.cols, er, ec, w);
+                double prr[9];
+#pragma unroll
+                for (int j = 0; j < 9; ++j) prr[j] = a.prior[j];
+                const uint32_t last = static_cast<uint32_t>(kKOfRing >> (4 * rc)) & 0xFu;
+                // (the guarded division-free comparison first: it hands over to the 26 divisions of the literal
+                // sequence only within 2^-46 of a boundary, so the pick is the reference's either way)
+                const int idx = choose_move(w, prr, 1.0, restriction_of(last), words_to_uniform(w0, w1), true);
+                nc = static_cast<uint32_t>(kRingOfK >> (4 * idx)) & 0xFu;
+                br = er; bc = ec;
+            }
+        }
+        row = br + static_cast<int>((kRingDr >> (2u * nc)) & 3u) - 1;
+        col = bc + static_cast<int>((kRingDc >> (2u * nc)) & 3u) - 1;
+        rc = nc;
+        ++k;
+        const uint32_t hr = static_cast<uint32_t>(row - win_r0), hc = static_cast<uint32_t>(col - win_c0);
+        if (hr < static_cast<uint32_t>(kWinRows) && hc < static_cast<uint32_t>(kWinCols)) {
+            atomicAdd(&s_win[hr * kWinCols + hc], 1u);
+        } else {
+            atomicAdd(&a.hist[static_cast<uint32_t>(row) * ucols + static_cast<uint32_t>(col)], 1u);
+            ++win_stray;
+        }
+    };
+
+    int it = 0;
+    uint32_t n_pairs = 0, n_slow = 0;                         // wave-uniform
+    const unsigned long long t_begin = a.debug_roam ? __builtin_amdgcn_s_memtime() : 0ull;
+    auto one_pair = [&]() __attribute__((always_inline)) {
+        const uint4 w4 = philox_block(a.seed, track, static_cast<unsigned long long>(static_cast<uint32_t>(blk0 + (it >> 1))));
+        const uint32_t ufa = w4.x >> 16, ufb = w4.z >> 16;
+        const bool st_a = static_cast<uint32_t>(it - rel) < span, st_b = static_cast<uint32_t>(it + 1 - rel) < span;
+        // (copies into locals before any select: see k_step_thr on selects of captured variables)
+        const uint32_t q0 = E.x, qa = E.y, qb = E.z, qc = E.w;
+        const uint32_t rc0 = rc;
+        // ---- first move: the decode of k_step_thr's roaming variants (a reversal row is an ordinary row of
+        // the move along the heading with the prior's thresholds)
+        const bool rva = REV && q0 == kThrReversal;
+        const uint32_t eua = rva ? rev_e : q0, rcda = rva ? rev_rc : rc0;
+        const int32_t a1 = static_cast<int32_t>(ufa) - static_cast<int32_t>(eua & 0xFFFFu);
+        const int32_t a2 = static_cast<int32_t>(ufa) - static_cast<int32_t>(eua >> 16);
+        const uint32_t orda = static_cast<uint32_t>(kRingOrder >> __umul24(6u, rcda)) & 63u;
+        const uint32_t nega = (static_cast<uint32_t>(a1) >> 31) + (static_cast<uint32_t>(a2) >> 31);      // 2 - sel
+        const uint32_t nca = (rcda + 7u + ((orda >> (4u - 2u * nega)) & 3u)) & 7u;
+        const uint32_t q1 = nega == 2u ? qa : (nega == 1u ? qb : qc);          // the entry of the cell it leads to
+        const int wra = wr + static_cast<int>((kRingDr >> (2u * nca)) & 3u) - 1;
+        const int wca = wc + static_cast<int>((kRingDc >> (2u * nca)) & 3u) - 1;
+        // ---- second move
+        const bool rvb = REV && q1 == kThrReversal;
+        const uint32_t eub = rvb ? rev_e : q1, rcdb = rvb ? rev_rc : nca;
+        const int32_t b1 = static_cast<int32_t>(ufb) - static_cast<int32_t>(eub & 0xFFFFu);
+        const int32_t b2 = static_cast<int32_t>(ufb) - static_cast<int32_t>(eub >> 16);
+        const uint32_t ordb = static_cast<uint32_t>(kRingOrder >> __umul24(6u, rcdb)) & 63u;
+        const uint32_t negb = (static_cast<uint32_t>(b1) >> 31) + (static_cast<uint32_t>(b2) >> 31);
+        const uint32_t ncb = (rcdb + 7u + ((ordb >> (4u - 2u * negb)) & 3u)) & 7u;
+        const int wrb = wra + static_cast<int>((kRingDr >> (2u * ncb)) & 3u) - 1;
+        const int wcb = wca + static_cast<int>((kRingDc >> (2u * ncb)) & 3u) - 1;
+        // the next entry, before anything else is known.  A lane that takes the pair from the table ends on
+        // a cell of the raster; one that does not (it stands on a boundary cell, a flag entry, a near-tie)
+        // may point up to two rows outside it -- the index is clamped into the table (a negative one wraps to
+        // a large unsigned) and the lane looks its state up again below, so what it loads here is never used
+        const int cell_a = win_cell0 + wra * a.cols + wca, cell_b = win_cell0 + wrb * a.cols + wcb;
+        {
+            const uint32_t cb = static_cast<uint32_t>(cell_b) < last_cell ? static_cast<uint32_t>(cell_b) : last_cell;
+            const uint32_t sidx = fast ? ((cb << 3) | ncb) : 0u;
+            E = *reinterpret_cast<const uint4 *>(pair + (sidx << 4));
+        }
+        // ufi - T in {-1, 0}: within rounding of a boundary; T1 > T2 (d1 < d2): a flag entry
+        const bool special = (static_cast<uint32_t>(a1 + 1) < 2u) | (static_cast<uint32_t>(a2 + 1) < 2u) | (a1 < a2) |
+                             (static_cast<uint32_t>(b1 + 1) < 2u) | (static_cast<uint32_t>(b2 + 1) < 2u) | (b1 < b2);
+        const bool go = fast & st_a & st_b & !special;
+        // visits: into the block's histogram window in LDS (no branch: a lane that does not go, or whose visit
+        // falls outside the window, adds 0 to cell 0); a visit outside the window is a global atomic and a stray
+        const bool in_a = go & (static_cast<uint32_t>(wra) < static_cast<uint32_t>(kWinRows)) & (static_cast<uint32_t>(wca) < static_cast<uint32_t>(kWinCols));
+        const bool in_b = go & (static_cast<uint32_t>(wrb) < static_cast<uint32_t>(kWinRows)) & (static_cast<uint32_t>(wcb) < static_cast<uint32_t>(kWinCols));
+        atomicAdd(&s_win[in_a ? (wra << 8) + wca : 0], in_a ? 1u : 0u);        // ds_add_u32, nothing returned
+        atomicAdd(&s_win[in_b ? (wrb << 8) + wcb : 0], in_b ? 1u : 0u);
+        const bool out = go & !(in_a & in_b);
+        if (__builtin_expect(__any(out), 0)) {
+            if (go && !in_a) { atomicAdd(&a.hist[cell_a], 1u); ++win_stray; }
+            if (go && !in_b) { atomicAdd(&a.hist[cell_b], 1u); ++win_stray; }
+        }
+        k += go ? 2 : 0;
+        wr = go ? wrb : wr;
+        wc = go ? wcb : wc;
+        rc = go ? ncb : rc0;
+        const bool slow = (st_a | st_b) & !go;
+        ++n_pairs;
+        if (__builtin_expect(__any(slow), 0)) {
+            ++n_slow;
+            if (slow) {
+                if (fast) { row = win_r0 + wr; col = win_c0 + wc; }           // the state the lane stands on, as a cell again
+#pragma unroll 1
+                for (int h = 0; h < 2; ++h)
+                    if (static_cast<uint32_t>(it + h - rel) < span) slow_step(h ? w4.z : w4.x, h ? w4.w : w4.y);
+                enter(true);
+            }
+        }
+        it += 2;
+    };
+    for (; it + 8 <= a.steps; ) {
+        if (!__any(static_cast<uint32_t>(it - rel) < span || (it < rel && span != 0u))) break;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) one_pair();
+    }
+    for (; it < a.steps; ) {                                 // a.steps is even (host)
+        if (!__any(static_cast<uint32_t>(it - rel) < span || (it < rel && span != 0u))) break;
+        one_pair();
+    }
+    if (fast) { row = win_r0 + wr; col = win_c0 + wc; }
+    if ((threadIdx.x & 63) == 0 && n_pairs) {
+        atomicAdd(&ctl->roam_pairs, static_cast<unsigned long long>(n_pairs));
+        if (n_slow) atomicAdd(&ctl->roam_slow, static_cast<unsigned long long>(n_slow));
+        if (a.debug_roam) {
+            const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_begin;
+            atomicAdd(&ctl->dbg_tsum, dt);
+            atomicMax(&ctl->dbg_tmax, dt);
+            atomicAdd(&ctl->dbg_waves, 1ull);
+            atomicMax(&ctl->dbg_slowmax, (static_cast<unsigned long long>(n_slow) << 32) | n_pairs);
+        }
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < kWinRows * kWinCols; q += kBlock) {
+        const uint32_t n = s_win[q];
+        if (n) atomicAdd(&a.hist[static_cast<uint32_t>(win_r0 + q / kWinCols) * ucols + static_cast<uint32_t>(win_c0 + q % kWinCols)], n);
+    }
+    {
+        unsigned long long ws = win_stray;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ws += __shfl_down(ws, off);
+        if ((threadIdx.x & 63) == 0 && ws) atomicAdd(&ctl->strays, ws);
+    }
+    const bool active = live0 && span != 0u && k < static_cast<int>(a.max_k);
+    if (live0 && !active) {
+        if (a.lengths) a.lengths[t] = static_cast<int32_t>(k + 1);
+        if (a.end_rc) reinterpret_cast<uint32_t *>(a.end_rc)[t] = (static_cast<uint32_t>(row) & 0xFFFFu) | (static_cast<uint32_t>(col) << 16);
+    }
+    // one reservation per block, every lane keeps its slot, the dead leave tombstones (k_step_thr<6>)
+    __shared__ uint32_t s_surv[kBlock / 64 + 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nsurv = __popcll(__ballot(active));
+    if (lane == 0) s_surv[wv] = static_cast<uint32_t>(nsurv);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int q = 0; q < kBlock / 64; ++q) tot += s_surv[q];
+        s_surv[kBlock / 64] = tot ? atomicAdd(&ctl->count[out_slot][xcd], static_cast<uint32_t>(kBlock)) : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    const uint32_t basei = s_surv[kBlock / 64];
+    if (basei != 0xFFFFFFFFu) {
+        a.list_out[xcd * a.cap + basei + threadIdx.x] = active ? t : -1;
+        if (active) {
+            TrackState o;
+            o.pos = static_cast<int32_t>((static_cast<uint32_t>(row) & 0xFFFFu) | (static_cast<uint32_t>(col) << 16));
+            o.k = k;
+            o.dirs = static_cast<uint32_t>(kKOfRing >> (4 * rc)) & 0xFu;
+            o.aux = s.aux;
+            a.state[t] = o;
+        }
+    }
+    unsigned long long mv = live0 ? static_cast<unsigned long long>(k - s.k) : 0ull;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mv += __shfl_down(mv, off);
+    if (lane == 0 && mv) atomicAdd(&ctl->steps, mv);
+}
+
 // K3 binning: one block per step of the launch.  The coherent schedule keeps the
 // whole batch on a front a few raster rows deep, so one step's visits fall into
 // a window of a few rows: counted with LDS atomics, flushed with contiguous
@@ -2709,10 +3087,12 @@ __global__ __launch_bounds__(kBlock) void k_wander_keys(const int32_t *__restric
 }
 
 __global__ __launch_bounds__(1024) void k_deal_sorted(const uint32_t *__restrict__ sorted_keys, const int32_t *__restrict__ sorted,
-                                                     int32_t *__restrict__ list_out, TrackCtl *ctl, int out_slot, int zero_slot, uint32_t cap)
+                                                     int32_t *__restrict__ list_out, TrackCtl *ctl, int out_slot, int zero_slot, uint32_t cap,
+                                                     int contiguous)
 {
     // run of key k: [lo[k], lo[k + 1]) in the sorted order, dealt from position off[k] on
     __shared__ uint32_t lo[kWanderWindows + 3], off[kWanderWindows + 3];
+    __shared__ uint32_t s_fill;
     const uint32_t slots = cap * kXcd;
     constexpr uint32_t kRun = kXcd * kBlock;
     if (threadIdx.x <= kWanderWindows + 2) {
@@ -2726,12 +3106,31 @@ __global__ __launch_bounds__(1024) void k_deal_sorted(const uint32_t *__restrict
     }
     __syncthreads();
     if (threadIdx.x == 0) {
+        // contiguous deal: a block keeps `fill` of its kBlock slots (the rest are tombstones), chosen so that the
+        // live tracks make about one block per CU.  A block-window kernel holds 144 KB of LDS, one block per
+        // CU, and a divergent gather costs its CU ~4 clocks per lane: 44k survivors in 180 full blocks leave 76
+        // CUs idle while the others take 1030 clocks per step.
+        const uint32_t live = lo[kWanderWindows + 1];
+        uint32_t fill = kBlock;
+        if (contiguous) {
+            fill = (live + kDealBlocks - 1) / kDealBlocks;
+            fill = fill < 64u ? 64u : (fill > kBlock ? kBlock : fill);
+        }
         uint32_t run = 0;
-        for (int k = 0; k <= kWanderWindows; ++k) {                  // (key kWanderWindows + 1 = dead: not dealt)
-            off[k] = run;
-            run += (lo[k + 1] - lo[k] + kRun - 1) / kRun * kRun;
+        for (int pass = 0; pass < 2; ++pass) {
+            run = 0;
+            for (int k = 0; k <= kWanderWindows; ++k) {              // (key kWanderWindows + 1 = dead: not dealt)
+                off[k] = run;
+                const uint32_t blocks = (lo[k + 1] - lo[k] + fill - 1) / fill;
+                // round-robin deal: a window's run is whole blocks of EVERY list
+                run += contiguous ? blocks * kBlock : (blocks * kBlock + kRun - 1) / kRun * kRun;
+            }
+            run = (run + kRun - 1) / kRun * kRun;
+            if (run <= slots || fill == kBlock) break;
+            fill = kBlock;                                           // no room for the thinned blocks
         }
         off[kWanderWindows + 1] = run;
+        s_fill = fill;
         if (run > slots) {
             // no room for the padding (nearly every slot is live): dense deal, blocks may mix windows
             run = 0;
@@ -2745,6 +3144,7 @@ __global__ __launch_bounds__(1024) void k_deal_sorted(const uint32_t *__restrict
     __syncthreads();
     const uint32_t total = off[kWanderWindows + 1];                  // a multiple of kRun
     const bool dense = off[kWanderWindows + 2] != 0;
+    const uint32_t fill = s_fill;
     for (uint32_t g = blockIdx.x * 1024u + threadIdx.x; g < total; g += gridDim.x * 1024u) {
         int32_t t = -1;
         if (dense) {
@@ -2753,10 +3153,15 @@ __global__ __launch_bounds__(1024) void k_deal_sorted(const uint32_t *__restrict
             int k = 0;
 #pragma unroll
             for (int q = 1; q <= kWanderWindows; ++q) k += off[q] <= g ? 1 : 0;
-            const uint32_t j = lo[k] + (g - off[k]);
-            if (j < lo[k + 1]) t = sorted[j];
+            const uint32_t in_run = g - off[k], blk = in_run / kBlock, sl = in_run % kBlock;
+            const uint32_t j = lo[k] + blk * fill + sl;
+            if (sl < fill && j < lo[k + 1]) t = sorted[j];
         }
-        list_out[(g & (kXcd - 1)) * cap + (g >> 3)] = t;
+        // contiguous: list x takes positions [x total / 8, (x + 1) total / 8), whole blocks of ONE window each
+        // (total is a multiple of 8 blocks) -- an XCD then steps one or two windows and its L2 holds their
+        // part of the roam table; round-robin (round 2): every window on every XCD
+        if (contiguous) list_out[(g / (total / kXcd)) * cap + g % (total / kXcd)] = t;
+        else list_out[(g & (kXcd - 1)) * cap + (g >> 3)] = t;
     }
     if (blockIdx.x == 0 && threadIdx.x < kXcd) {
         ctl->count[out_slot][threadIdx.x] = total / kXcd;
@@ -2777,12 +3182,14 @@ struct Workspace {
     uint32_t *bucket;            // the same visits ordered by raster tile (oblique headings)
     uint32_t *tile_count, *tile_start, *tile_cursor, *item_start;   // [kTilesMax] each, item_start one more
     WanderWindows *wander;
+    RoamEntry *roam;             // kWanderWindows slabs (batches large enough for the wander sort), or nullptr
     uint32_t *visits;            // [kVisitSteps][visit_stride] visited cells of one launch
     long long visit_stride;
     uint32_t cap;                // slots per XCD list
 };
 
 constexpr int kVisitSteps = 1024;  // binning mode covers launches of up to this many steps
+constexpr int64_t kWanderMinTracks = 8192;   // smaller batches are never sorted into windows
 
 static size_t sort_temp_size(int64_t n)
 {
@@ -2838,6 +3245,7 @@ static size_t workspace_layout(int64_t n, char *base, Workspace *ws)
     off = align_up(off + sizeof(uint32_t) * (4 * kTilesMax + 1), 256);
     if (ws) ws->wander = reinterpret_cast<WanderWindows *>(base + off);
     off = align_up(off + sizeof(WanderWindows), 256);
+    if (ws) ws->roam = nullptr;             // (the pair table lives behind the regular workspace: pair_table_bytes)
     return off;
 }
 
@@ -2953,9 +3361,18 @@ extern "C" size_t ssrs_tracks_workspace_bytes(int64_t ntracks)
     return workspace_layout(ntracks, nullptr, nullptr);
 }
 
+// The pair table of a roaming batch (k_step_roam): 8 x 16 bytes per cell, behind the regular workspace; only
+// batches large enough for the wander sort roam in block windows, and its byte offsets are 32-bit
+static size_t pair_table_bytes(int64_t ntracks, int rows, int cols)
+{
+    if (ntracks < kWanderMinTracks || rows <= 0 || cols <= 0) return 0;
+    const size_t cells = static_cast<size_t>(rows) * static_cast<size_t>(cols);
+    return cells < kPairMaxCells ? align_up(cells * 8 * sizeof(RoamEntry), 256) : 0;
+}
+
 extern "C" size_t ssrs_tracks_workspace_bytes_ex(int64_t ntracks, int rows, int cols, int hist_copies)
 {
-    const size_t base = align_up(ssrs_tracks_workspace_bytes(ntracks), 256);
+    const size_t base = align_up(ssrs_tracks_workspace_bytes(ntracks), 256) + pair_table_bytes(ntracks, rows, cols);
     if (rows <= 0 || cols <= 0 || hist_copies < 2) return base;
     if (hist_copies > 64) hist_copies = 64;
     return base + static_cast<size_t>(hist_copies) * static_cast<size_t>(rows) * static_cast<size_t>(cols) * sizeof(uint32_t);
@@ -3166,6 +3583,7 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
     a.cap = ws.cap;
     a.thr = ws.thr;
     a.wander = ws.wander;
+    a.debug_roam = std::getenv("SSRS_TRACKS_DEBUG_ROAM") != nullptr ? 1 : 0;
     a.vcap = ws.cap;
     const bool lean = p->memory_parameter == 1 && traj == nullptr;
     const bool ring = (p->flags & SSRS_TRACKS_RING_TABLE) != 0;
@@ -3227,13 +3645,33 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
     bool cached = cache_ok && scattered;
     bool want_wander_sort = cached;
     int wander_sorts = 0, wander_cooldown = 0, stable_batches = 0, upper_from = 0;
+    size_t ws_base = align_up(ssrs_tracks_workspace_bytes(ntracks), 256);
+    // room behind the regular workspace: first the pair table of the roaming regime (threshold stepper only)
+    {
+        const size_t pb = thr ? pair_table_bytes(ntracks, p->rows, p->cols) : 0;
+        if (pb && workspace_bytes >= ws_base + pb) {
+            ws.roam = reinterpret_cast<RoamEntry *>(static_cast<char *>(workspace) + ws_base);
+            ws_base += pb;
+        }
+        a.roam = ws.roam;
+    }
+    // pair table (k_step_roam): built when the batch starts to roam; A/B switches SSRS_TRACKS_NO_ROAM_TABLE, SSRS_TRACKS_DEAL_ROUND_ROBIN
+    const bool roam_ok = cache_ok && ws.roam != nullptr && std::getenv("SSRS_TRACKS_NO_ROAM_TABLE") == nullptr;
+    const bool roam_rev = thr_prior.rev_ok != 0 && std::getenv("SSRS_TRACKS_NO_REV") == nullptr;
+    const bool deal_contiguous = std::getenv("SSRS_TRACKS_DEAL_ROUND_ROBIN") == nullptr;
+    bool roam_ready = false;
+    int roam_launches = 0, stable_roam = 0;
+    int roam_steps = 128 * S;                // A/B: SSRS_TRACKS_ROAM_STEPS (4096: 0.0073, 16384: 0.0060, 65536: 0.0053 ns per step at C2)
+    if (const char *e = std::getenv("SSRS_TRACKS_ROAM_STEPS")) {
+        const int v = std::atoi(e);
+        if (v >= 2 && v <= (1 << 20)) roam_steps = v & ~1;
+    }
     uint32_t prev_total = 0;
     // (the key arrays hold 2 n words >= the list slots; the coarse grid of k_wander_windows fits its LDS)
-    const bool wander_sort_ok = ntracks >= 8192 &&
+    const bool wander_sort_ok = ntracks >= kWanderMinTracks &&
                                 static_cast<long long>((p->rows + kBinRows - 1) / kBinRows) * ((p->cols + kBinCols - 1) / kBinCols) <= kWanderBins;
     // private histogram copies live behind the regular workspace when the caller gave room
     const size_t ncell = static_cast<size_t>(p->rows) * static_cast<size_t>(p->cols);
-    const size_t ws_base = align_up(ssrs_tracks_workspace_bytes(ntracks), 256);
     int ncopies = 0;
     if (hist && workspace_bytes > ws_base) ncopies = static_cast<int>((workspace_bytes - ws_base) / (ncell * sizeof(uint32_t)));
     uint32_t *extra = reinterpret_cast<uint32_t *>(static_cast<char *>(workspace) + ws_base);
@@ -3314,20 +3752,34 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                 break;
             }
             hipLaunchKernelGGL(k_deal_sorted, dim3(64), dim3(1024), 0, st, k1, sorted, ws.list[(launch + 1) & 1], ws.ctl,
-                               (launch + 1) & 3, (launch + 2) & 3, ws.cap);
+                               (launch + 1) & 3, (launch + 2) & 3, ws.cap, deal_contiguous ? 1 : 0);
             ++launch;
             ++wander_sorts;
             want_wander_sort = false;
             want_rebalance = false;
             wander_cooldown = 3;
+            stable_roam = 0;
             marks_adjacent = false;
             // the padded deal makes the lists LONGER (each window's run is rounded up to whole blocks of
             // every list): raise the bound now, and let no batch queued before this point lower it
-            const unsigned long long padded = static_cast<unsigned long long>(upper) + (kWanderWindows + 1ull) * kBlock;
+            // (thinned blocks: at most kDealBlocks + one per window + the padding, 264 blocks = 33 per list)
+            unsigned long long padded = static_cast<unsigned long long>(upper) + (kWanderWindows + 1ull) * kBlock;
+            if (deal_contiguous && padded < 34ull * kBlock) padded = 34ull * kBlock;
             upper = padded > ws.cap ? ws.cap : static_cast<uint32_t>(padded);
             upper_from = batches;
         }
         if (cached) want_rebalance = false;          // (the lists carry tombstones; the wander sort deals evenly)
+        if (cached && roam_ok && !roam_ready) {
+            // the batch starts to roam: the pair table, for the whole raster (~2 ms at 5000 x 6000)
+            const char *tabc = reinterpret_cast<const char *>(table);
+            const unsigned grid = 256 * 16;
+            if (roam_rev) hipLaunchKernelGGL(k_roam_build<true>, dim3(grid), dim3(kBlock), 0, st, tabc, a.guard, a.plane_shift, p->rows, p->cols,
+                                             ws.roam, thr_prior);
+            else hipLaunchKernelGGL(k_roam_build<false>, dim3(grid), dim3(kBlock), 0, st, tabc, a.guard, a.plane_shift, p->rows, p->cols,
+                                    ws.roam, thr_prior);
+            roam_ready = true;
+            marks_adjacent = false;
+        }
         if (want_rebalance && launch > 0) {
             // pseudo-launch: list[launch & 1] -> list[(launch + 1) & 1], counts likewise
             hipLaunchKernelGGL(k_rebalance_lists, dim3(1), dim3(1024), 0, st, ws.list[launch & 1], ws.list[(launch + 1) & 1],
@@ -3355,8 +3807,11 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
             uint32_t vcap_l = ws.cap;
             long long vstride_l = ws.visit_stride;
             if (thr && !first_move && cached && !(rec && rec->complete) && grow_steps) {
-                // no visit buffer to fit: only the read-back interval matters
-                Sl = 8 * S;
+                // no visit buffer to fit: only the read-back interval matters.  Once the roam table is in use the
+                // launches are long: a launch lasts as long as its slowest wave (a lane on the slow path --
+                // near-ties, a track that leaves its region on its way out of the basin -- holds its wave
+                // back), and over more steps the waves' slow episodes average out
+                Sl = (roam_ok && roam_ready && stable_roam >= 2) ? roam_steps : 8 * S;
             } else if (thr && !first_move && (binning_on || tiles_on) && !(rec && rec->complete) && grow_steps) {
                 // Few live tracks left (the long tail of a batch; tracks that wander until max_moves):
                 // the visit buffer then holds MORE iterations of the shrunken lists, and a launch of
@@ -3454,6 +3909,24 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                     if (cached && !a.visits) {
                         ++block_window_launches;
                         batch_block_window = is_block_window = true;
+                        if (roam_ok && roam_ready) {
+                            ++roam_launches;
+                            if (rev) hipLaunchKernelGGL(k_step_roam<true>, dim3(blocks), dim3(kBlock), 0, st, a, thr_prior);
+                            else hipLaunchKernelGGL(k_step_roam<false>, dim3(blocks), dim3(kBlock), 0, st, a, thr_prior);
+                            if (a.debug_roam) {
+                                // diagnostics only: one synchronous read of the control block per launch
+                                TrackCtl c;
+                                (void)hipMemcpyAsync(&host_counts[kFinalSlot], ws.ctl, sizeof(TrackCtl), hipMemcpyDeviceToHost, st);
+                                (void)hipStreamSynchronize(st);
+                                memcpy(&c, &host_counts[kFinalSlot], sizeof(TrackCtl));
+                                if (c.dbg_waves)
+                                    fprintf(stderr, "[roam] launch %d blocks %u Sl %d: %llu waves, mean %.0f clk, max %.0f clk (x%.2f); slowest-by-slow-pairs wave: %llu of %llu pairs slow\n",
+                                            launch, blocks, Sl, c.dbg_waves, static_cast<double>(c.dbg_tsum) / c.dbg_waves, static_cast<double>(c.dbg_tmax),
+                                            static_cast<double>(c.dbg_tmax) * c.dbg_waves / static_cast<double>(c.dbg_tsum), c.dbg_slowmax >> 32, c.dbg_slowmax & 0xFFFFFFFFull);
+                                (void)hipMemsetAsync(&ws.ctl->dbg_tsum, 0, 4 * sizeof(unsigned long long), st);
+                            }
+                            break;
+                        }
                         if (rev) hipLaunchKernelGGL((k_step_thr<6, false, true>), dim3(blocks), dim3(kBlock), 0, st, a, thr_prior);
                         else hipLaunchKernelGGL((k_step_thr<6>), dim3(blocks), dim3(kBlock), 0, st, a, thr_prior);
                         break;
@@ -3633,6 +4106,7 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                             dsteps ? static_cast<double>(dstray) / static_cast<double>(dsteps) : 0.0, total);
                 if (wander_cooldown > 0) --wander_cooldown;
                 else if (dsteps > 0 && dstray * 64 > dsteps && wander_sorts < 12) want_wander_sort = true;
+                else ++stable_roam;                     // settled in its windows: the launches may grow
             }
             // batches that never binned (small, unsorted, very wide rasters) give no stray
             // signal: tracks still alive after four raster crossings are wandering
@@ -3669,6 +4143,9 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
         stats->tile_launches = tile_launches;
         stats->block_window_launches = block_window_launches;
         stats->wander_sorts = wander_sorts;
+        stats->roam_launches = roam_launches;
+        stats->roam_wave_pairs = static_cast<int64_t>(host_ctl.roam_pairs);
+        stats->roam_slow_wave_pairs = static_cast<int64_t>(host_ctl.roam_slow);
         // (batches still unexamined when the loop ended: the last one or two of the run)
         stats->block_window_steps = block_window_steps;
         float ms = 0.f;

@@ -344,7 +344,10 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
                            first_move_ms=float(stats.first_move_ms), recorded=bool(recorded),
                            block_window_ms=float(stats.block_window_ms),
                            block_window_timed=int(stats.block_window_timed),
-                           block_window_steps=int(stats.block_window_steps)))
+                           block_window_steps=int(stats.block_window_steps),
+                           roam_launches=int(stats.roam_launches),
+                           roam_wave_pairs=int(stats.roam_wave_pairs),
+                           roam_slow_wave_pairs=int(stats.roam_slow_wave_pairs)))
 
 
 def generate_simulated_tracks(move_dirn, start_location, grid_shape, memory_parameter=1,

@@ -43,7 +43,7 @@ def test_roaming_batch_vs_oracle_at_c2(c2_field):
     got = movmodel.simulate_tracks(0., starts, SHAPE, 1, 1., f['upd'], f['pot'], seed=30, max_moves=CAP)
     st = got.stats
     # the batch really went through the roaming machinery
-    assert st['block_window_launches'] > 0 and st['wander_sorts'] > 0, st
+    assert st['block_window_launches'] > 0 and st['wander_sorts'] > 0 and st['roam_launches'] > 0, st
     lengths = got.lengths.cpu().numpy()
     assert np.array_equal(lengths, ref['lengths'])
     assert np.array_equal(got.ends.cpu().numpy(), ref['ends'])
@@ -53,15 +53,18 @@ def test_roaming_batch_vs_oracle_at_c2(c2_field):
     at_cap = float(np.mean(lengths - 1 >= CAP))
     assert 0.25 < at_cap < 0.6, at_cap          # the basins hold 30-45 % of a batch on this field
     f['shared']['survivors'] = at_cap
-    # the same batch through the tile buckets only (A/B switch of the block windows): same integers
+    # the same batch through the tile buckets only / through round 2's one-gather-per-move kernel
+    # (A/B switches of the block windows and of the roam table): same integers
     import os
-    os.environ['SSRS_TRACKS_NO_BLOCK_WINDOW'] = '1'
-    try:
-        alt = movmodel.simulate_tracks(0., starts, SHAPE, 1, 1., f['upd'], f['pot'], seed=30, max_moves=CAP)
-    finally:
-        del os.environ['SSRS_TRACKS_NO_BLOCK_WINDOW']
-    assert alt.stats['block_window_launches'] == 0
-    assert torch.equal(alt.lengths, got.lengths) and torch.equal(alt.hist, got.hist)
+    for switch in ('SSRS_TRACKS_NO_BLOCK_WINDOW', 'SSRS_TRACKS_NO_ROAM_TABLE'):
+        os.environ[switch] = '1'
+        try:
+            alt = movmodel.simulate_tracks(0., starts, SHAPE, 1, 1., f['upd'], f['pot'], seed=30, max_moves=CAP)
+        finally:
+            del os.environ[switch]
+        assert alt.stats['roam_launches'] == 0
+        assert (alt.stats['block_window_launches'] == 0) == (switch == 'SSRS_TRACKS_NO_BLOCK_WINDOW')
+        assert torch.equal(alt.lengths, got.lengths) and torch.equal(alt.hist, got.hist), switch
 
 
 def test_uncapped_batch_properties_at_c2(c2_field):

@@ -873,10 +873,11 @@ def test_block_windows_for_batches_that_roam_basins(gpu):
     got = movmodel.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=4, use_table=True, thr=True,
                                    max_moves=cap, steps_per_launch=128)
     assert got.stats['block_window_launches'] > 0 and got.stats['wander_sorts'] > 0, got.stats
+    assert got.stats['roam_launches'] > 0, got.stats             # two moves per 64-byte roam-table entry (k_step_roam)
     assert np.array_equal(got.lengths.cpu().numpy(), ref['lengths'])
     assert np.array_equal(got.ends.cpu().numpy(), ref['ends'])
     assert np.array_equal(got.hist.cpu().numpy().view(np.uint32), ref['hist'])
-    for switch in ('SSRS_TRACKS_NO_BLOCK_WINDOW', 'SSRS_TRACKS_NO_REV'):
+    for switch in ('SSRS_TRACKS_NO_BLOCK_WINDOW', 'SSRS_TRACKS_NO_ROAM_TABLE', 'SSRS_TRACKS_DEAL_ROUND_ROBIN', 'SSRS_TRACKS_NO_REV'):
         os.environ[switch] = '1'
         try:
             other = movmodel.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=4, use_table=True, thr=True,
@@ -884,6 +885,8 @@ def test_block_windows_for_batches_that_roam_basins(gpu):
         finally:
             del os.environ[switch]
         assert torch.equal(other.hist, got.hist) and torch.equal(other.lengths, got.lengths), switch
+        if switch == 'SSRS_TRACKS_NO_ROAM_TABLE':
+            assert other.stats['roam_launches'] == 0 and other.stats['block_window_launches'] > 0
     del os.environ['SSRS_TRACKS_FIXED_STEPS']
     assert other.stats['block_window_launches'] > 0            # (the last switch only changes the kernel variant)
     grown = movmodel.simulate_tracks(0., starts, (rows, cols), 1, 1., upd, pot, seed=4, use_table=True, thr=True,
@@ -920,7 +923,7 @@ def test_block_windows_when_nearly_every_track_is_trapped(gpu):
     finally:
         del os.environ['SSRS_TRACKS_FIXED_STEPS']
     assert got.stats['block_window_launches'] > 0 and got.stats['wander_sorts'] > 0, got.stats
-    assert sc.stats['block_window_launches'] > 0, sc.stats
+    assert sc.stats['block_window_launches'] > 0 and sc.stats['roam_launches'] > 0, sc.stats
     for res in (got, sc):
         assert np.array_equal(res.lengths.cpu().numpy(), ref['lengths'])
         assert np.array_equal(res.ends.cpu().numpy(), ref['ends'])
