@@ -41,10 +41,13 @@ STEP_BYTES = 76                 # 9x4 + 9x4 window + 4 B point/R
 RASTER_BYTES_PER_CELL = 20      # fused K1 as benchmarked: f64 DEM in (8) + f32 out (4)
 #                                 + f64 usable out (8); SURVEY's 12 B/cell figure is
 #                                 the f32-in/f32-out elementwise kernel
-# steps/s of the stepper once the GPU is FULL of waves (1 M tracks per GPU on the ramp, every SIMD
-# holding several waves: profiles/r02_scale_tracks.txt, 40.6 M tracks/s x 4 850 steps): what a
-# latency-bound batch of 100k tracks is measured against (`throughput_frac`)
+# steps/s of the stepper once the GPU is FULL of waves: what a latency-bound batch of 100k tracks is
+# measured against (`throughput_frac`).  Front-shaped batches (k_step_thr<4>): 1 M tracks per GPU on the
+# ramp, every SIMD holding several waves (profiles/r02_scale_tracks.txt, 40.6 M tracks/s x 4 850 steps).
+# Roaming batches (k_step_roam, one block of 144 KB LDS per CU): every CU holding a FULL block of 256 tracks
+# (profiles/r03_roam_fill.txt)
 THROUGHPUT_BOUND_STEPS_PER_S = 2.0e11
+ROAM_THROUGHPUT_BOUND_STEPS_PER_S = 2.9e11
 
 
 def parse():
@@ -227,7 +230,7 @@ class Passes:
         self.acc = dict(raster_ms=0.0, table_ms=0.0, step_kernel_ms=0.0, step_wall_ms=0.0, hist_ms=0.0, steps=0,
                         launches=0, timed_launches=0, first_move_ms=0.0, block_window_ms=0.0, block_window_timed=0,
                         block_window_steps=0, block_window_launches=0, window_launches=0, tile_launches=0,
-                        wander_sorts=0)
+                        wander_sorts=0, roam_launches=0, roam_wave_pairs=0, roam_slow_wave_pairs=0, roam_fine_settled=0)
 
     def one_step(self, timed):
         args, ev, acc = self.args, self.ev, self.acc
@@ -264,7 +267,8 @@ class Passes:
             acc['hist_ms'] += st['hist_ms']
             acc['steps'] += st['total_steps']
             for k in ('launches', 'timed_launches', 'first_move_ms', 'block_window_ms', 'block_window_timed',
-                      'block_window_steps', 'block_window_launches', 'window_launches', 'tile_launches', 'wander_sorts'):
+                      'block_window_steps', 'block_window_launches', 'window_launches', 'tile_launches', 'wander_sorts',
+                      'roam_launches', 'roam_wave_pairs', 'roam_slow_wave_pairs', 'roam_fine_settled'):
                 acc[k] += st.get(k, 0)
         return out
 
@@ -306,12 +310,18 @@ def stepper_roofline(args, acc, K, solved):
     table_path = not (args.direct or args.f64_table or args.exact_only or args.ring_table)
     moved_bytes = 76 if args.direct else (92 if args.exact_only else (28 if args.f64_table else (16 if args.ring_table else 8)))
     bw_share = acc['block_window_ms'] / acc['step_kernel_ms'] if acc['step_kernel_ms'] > 0 else 0.0
+    bound_sps = THROUGHPUT_BOUND_STEPS_PER_S
     if solved and table_path and bw_share > 0.5:
-        # the pass is dominated by the block-window launches of the roaming survivors: one 4-byte
-        # table entry per step, the visit is counted in LDS
+        # the pass is dominated by the block-window launches of the roaming survivors; the visits are counted in LDS
         ms, steps, n = acc['block_window_ms'], acc['block_window_steps'], acc['block_window_timed']
-        bytes_per_step = 4
-        name = 'k_step_thr<6, false, true> (K2 stepper, block histogram windows; rank 0)'
+        if acc.get('roam_launches', 0) * 2 > acc['block_window_launches']:
+            # pair table: one 16-byte entry per PAIR of moves
+            bytes_per_step = 8
+            name = 'k_step_roam<true> (K2 stepper of roaming batches: pair table, two moves per 16-byte gather, block histogram windows in LDS; rank 0)'
+            bound_sps = ROAM_THROUGHPUT_BOUND_STEPS_PER_S
+        else:
+            bytes_per_step = 4          # one 4-byte threshold entry per move
+            name = 'k_step_thr<6, false, true> (K2 stepper, block histogram windows; rank 0)'
     else:
         first_moves = K if acc['first_move_ms'] > 0 else 0
         n = acc['timed_launches'] - first_moves
@@ -326,7 +336,8 @@ def stepper_roofline(args, acc, K, solved):
     sps = steps / sec if sec > 0 else 0.0
     return {
         'kernel': name,
-        # what bounds it: the dependent chain of one step (gather -> decode -> next address), not HBM
+        # what bounds it: the dependent chain of one step (divergent gather -> decode -> next address) in
+        # waves that are alone on their SIMDs, not HBM (the tables stay in L2: TCC hit rate 99.8 %)
         'bound': 'latency',
         # achieved = bytes the shipped data path really requests per step x steps / sum of this
         # kernel's launch durations
@@ -339,8 +350,8 @@ def stepper_roofline(args, acc, K, solved):
         'steps_per_s_in_kernel': sps,
         # the number that can approach 1: steps/s of this kernel against the stepper's measured rate
         # with the GPU full of waves (a latency-bound batch leaves SIMDs idle)
-        'throughput_frac': sps / THROUGHPUT_BOUND_STEPS_PER_S,
-        'throughput_bound_steps_per_s': THROUGHPUT_BOUND_STEPS_PER_S,
+        'throughput_frac': sps / bound_sps,
+        'throughput_bound_steps_per_s': bound_sps,
         'first_move_launch_ms': acc['first_move_ms'] / max(K, 1),
         # SURVEY 8(d)'s 76 B/step is the gather volume of the REFERENCE's formulation (18 window
         # reads + 1 point); the shipped path precomputes the windows into a table, so this
@@ -496,8 +507,9 @@ def main():
             'stepper_path': ('direct 3x3 gathers' if args.direct else
                              ('f64 transition table' if (args.f64_table or args.exact_only)
                               else ('f32 ring table, exact fallback on the raw windows' if args.ring_table else
-                                    'threshold table (two 16-bit decision thresholds per cell and last move), '
-                                    'exact fallback on the raw windows'))),
+                                    'threshold table (two 16-bit decision thresholds per cell and last move); once the batch roams, '
+                                    'the pair table (a state\'s thresholds and its three successors\', two moves per 16-byte gather) '
+                                    'and a 32-bit table for near-ties; exact fallback on the raw windows'))),
             'potential': pot_label,
         },
         # tracks/s depends on the terrain through the track lengths: the comparable figure is steps/s
@@ -508,7 +520,11 @@ def main():
         'share_at_max_moves': float(np.mean(L >= max_moves)), 'max_moves': max_moves,
         'launches_per_step': {'all': acc['launches'] // K, 'row_window': acc['window_launches'] // K,
                               'tile_buckets': acc['tile_launches'] // K, 'block_windows': acc['block_window_launches'] // K,
-                              'wander_sorts': acc['wander_sorts'] // K},
+                              'wander_sorts': acc['wander_sorts'] // K, 'pair_table': acc['roam_launches'] // K},
+        'roam': {'wave_pairs': acc['roam_wave_pairs'] // K, 'slow_wave_pairs': acc['roam_slow_wave_pairs'] // K,
+                 'near_ties_settled_at_32_bits': acc['roam_fine_settled'] // K,
+                 'what': 'pair-table launches: pairs of moves run by their waves; how many sent a lane through the '
+                         'single-move sequence (near-ties, flag entries); near-ties the 32-bit fine table settled'},
         'raster_mcells_per_s': ncells / raster_s / 1e6 if raster_s > 0 else None,
         'raster_gbps': ncells * RASTER_BYTES_PER_CELL / raster_s / 1e9 if raster_s > 0 else None,
         'phase_ms_per_step': {

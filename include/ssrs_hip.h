@@ -204,7 +204,7 @@ typedef struct SsrsTrackStats {
                                      read-backs; a batch is one or two launches of one kind) */
     int32_t roam_launches;        /* block-window launches that stepped through the windows' roam table
                                      (two moves per 64-byte entry, k_step_roam) */
-    int32_t reserved0;
+    int32_t reserved0;            /* near-ties those launches settled with the 32-bit fine table */
     int64_t roam_wave_pairs;      /* pairs of moves run by the waves of those launches ... */
     int64_t roam_slow_wave_pairs; /* ... and how many of them sent some lane through the single-move sequence
                                      (near-ties, flag entries, moves out of the window, burn-in) */
@@ -261,7 +261,8 @@ int ssrs_transition_thr_build(const double *updraft, const float *potential, con
  * windows of 144 x 256 cells and counted in LDS (SsrsTrackStats.block_window_launches);
  * nothing to size for it. */
 size_t ssrs_tracks_workspace_bytes(int64_t ntracks);
-/* The same plus (i) the pair table of the roaming regime -- 128 bytes per cell (3.84 GB at 5000 x 6000),
+/* The same plus (i) the pair table of the roaming regime and the fine table of its near-ties -- 128 + 64
+ * bytes per cell (5.76 GB at 5000 x 6000),
  * batches of >= 8192 tracks on rasters below 2^25 cells: with it the block-window launches take two moves
  * per 16-byte gather (SsrsTrackStats.roam_launches), without it they run round 2's one-gather-per-move
  * kernel, 2.1x slower -- and (ii) room for `hist_copies` (2..64) private copies of the histogram.  A

@@ -690,6 +690,7 @@ struct StepArgs {
     int ncopies;
     const WanderWindows *wander; // k_step_thr<6>: the windows of the last wander sort (n = 0: none yet)
     const RoamEntry *roam;       // k_step_roam: the pair table (8 entries per cell of the raster), or NULL
+    const void *fine;            // k_step_roam: 32-bit boundaries per (cell, last move) for near-ties, or NULL
     int debug_roam;              // k_step_roam: wave lifetimes into the control block (SSRS_TRACKS_DEBUG_ROAM)
     uint32_t vis_r, vis_c;       // visit key = row * vis_r + col * vis_c: (cols, 1), or (1, rows) when
                                  // the front is a column (east / west headings: transposed binning)
@@ -2102,6 +2103,102 @@ __global__ __launch_bounds__(kBlock) void k_roam_build(const char *__restrict__ 
     }
 }
 
+// Near-ties.  0.6 % of a roaming wave's pairs have a lane whose uniform lies within one unit (2^-16) of a
+// threshold; the reference's exact sequence on the raw windows then costs that wave ~25 000 clocks (18 + 26
+// f64 divisions in a lone wave), a sixth of its time, and the launch waits for the wave that drew the most of
+// them.  The fine table holds the same two boundaries per (cell, last move) as 32-bit fixed point, computed
+// in f64 from the reference's own weights (movmodel.py:292-306: harmonic mean x f32 potential difference x
+// f32 1/norm, clipped at 0): |T - 2^32 cdf_k/cdf_8| <= 0.5 + 2^32 x ~1e-15 (x = a / (a + b + c) against
+// the reference's normalise-twice-and-divide: a dozen roundings of 2^-53), and the uniform's top 32 bits
+// u32 satisfy u32 <= 2^32 u < u32 + 1, so u32 - T >= 1 means cdf <= u, u32 - T <= -2 means it is not, and only
+// u32 - T in {-1, 0} (5e-10 per boundary) still needs the exact sequence.  Rows the 16-bit table flags
+// (boundary, poison, reversal) and rows whose weights are not finite are flags here too (T1 > T2).
+struct FineEntry { uint32_t t1, t2; };
+struct FinePrior { uint32_t zero_t1[8], zero_t2[8], reversal; };     // the masked prior's boundaries after last move rc
+
+__host__ __device__ __forceinline__ uint32_t fine_fixed(double x)
+{   // round(2^32 x) for x in [0, 1], half up, clamped
+    const double v = x * 4294967296.0 + 0.5;
+    return v >= 4294967295.0 ? 0xFFFFFFFFu : static_cast<uint32_t>(static_cast<unsigned long long>(v));
+}
+
+template <bool HAS_POT>
+__global__ __launch_bounds__(kBlock) void k_fine_build(const double *__restrict__ updraft, const float *__restrict__ potential,
+                                                      FineEntry *__restrict__ out, int rows, int cols, int tiles_x, int ntiles,
+                                                      const FinePrior fp)
+{
+    // the weights exactly as k_transition_table forms them (LDS tile of the clipped updraft's reciprocals
+    // and of the potential: identical operands, identical bits)
+    constexpr int LW = kTabW + 2, LH = kTabH + 2;
+    __shared__ double s_inv[LW * LH];
+    __shared__ float s_pot[LW * LH];
+    const int t = xcd_band(blockIdx.x, ntiles);
+    const int r0 = (t / tiles_x) * kTabH, c0 = (t % tiles_x) * kTabW;
+    for (int i = threadIdx.x; i < LW * LH; i += kBlock) {
+        const int lr = i / LW, lc = i - lr * LW;
+        int gr = r0 - 1 + lr, gc = c0 - 1 + lc;
+        gr = gr < 0 ? 0 : (gr >= rows ? rows - 1 : gr);
+        gc = gc < 0 ? 0 : (gc >= cols ? cols - 1 : gc);
+        const size_t g = static_cast<size_t>(gr) * cols + gc;
+        const double v = updraft[g];
+        const double w = v != v ? v : (v > 1e-06 ? v : 1e-06);   // clip(min=1e-06), NaN kept
+        s_inv[i] = 1.0 / w;
+        s_pot[i] = HAS_POT ? potential[g] : 0.f;
+    }
+    __syncthreads();
+    const int lc = static_cast<int>(threadIdx.x % kTabW) + 1;
+    const int col = c0 + lc - 1;
+    if (col >= cols) return;
+    for (int lr = static_cast<int>(threadIdx.x / kTabW) + 1; lr <= kTabH; lr += kBlock / kTabW) {
+        const int row = r0 + lr - 1;
+        if (row >= rows) break;
+        const size_t cell = static_cast<size_t>(row) * cols + col;
+        const bool interior = row > 0 && col > 0 && row < rows - 1 && col < cols - 1;
+        double w[9];
+        bool bad = !interior;
+        if (interior) {
+            const double ic = s_inv[lr * LW + lc];
+            const float pc = s_pot[lr * LW + lc];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const int o = (lr + dr_of(j)) * LW + lc + dc_of(j);
+                w[j] = 2.0 / (ic + s_inv[o]);                       // harmonic mean
+                if (HAS_POT) {
+                    const float d = pc - s_pot[o];
+                    const float ninv = (j == 4) ? 0.f : ((j & 1) ? 1.f : SSRS_NINV_DIAG);
+                    const float e = d * ninv;                       // stays f32
+                    w[j] = w[j] * static_cast<double>(e);
+                }
+                bad |= !(w[j] - w[j] == 0.0);                       // NaN or infinite (the centre's too: movmodel.py:228)
+                w[j] = w[j] > 0.0 ? w[j] : 0.0;                     // clip(min=0)
+            }
+        }
+        FineEntry en[8];
+#pragma unroll
+        for (int rc = 0; rc < 8; ++rc) {
+            const uint32_t ord = ring_order(rc);
+            const int ring3[3] = {(rc + 7) % 8, rc, (rc + 1) % 8};
+            const int ka = kRingK[ring3[ord & 3u]], kb = kRingK[ring3[(ord >> 2) & 3u]], kc = kRingK[ring3[(ord >> 4) & 3u]];
+            FineEntry e = {0xFFFFFFFFu, 0u};                         // flag
+            if (!bad) {
+                const double ab = w[ka] + w[kb], tot = ab + w[kc];   // np.cumsum's order
+                if (tot == 0.0) {
+                    // all three weights zero: the masked prior decides (movmodel.py:234-238), unless it is empty too
+                    if (!((fp.reversal >> rc) & 1u)) { e.t1 = fp.zero_t1[rc]; e.t2 = fp.zero_t2[rc]; }
+                } else if (tot - tot == 0.0) {                       // finite
+                    e.t1 = fine_fixed(w[ka] / tot);
+                    e.t2 = fine_fixed(ab / tot);
+                    if (e.t1 > e.t2) e.t1 = e.t2;                    // (a <= a + b up to rounding)
+                }
+            }
+            en[rc] = e;
+        }
+        uint4 *dst = reinterpret_cast<uint4 *>(out + cell * 8);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[q] = make_uint4(en[2 * q].t1, en[2 * q].t2, en[2 * q + 1].t1, en[2 * q + 1].t2);
+    }
+}
+
 template <bool REV>
 __global__ __launch_bounds__(kBlock) void k_step_roam(const StepArgs a, const ThrPrior pr)
 {
@@ -2186,7 +2283,8 @@ __global__ __launch_bounds__(kBlock) void k_step_roam(const StepArgs a, const Th
     const char *tab = reinterpret_cast<const char *>(a.table);
     const uint32_t psh = static_cast<uint32_t>(a.plane_shift);
     const uint32_t rev_e = pr.rev_e, rev_rc = pr.rev_rc;
-    uint32_t win_stray = 0;
+    uint32_t win_stray = 0, n_fine = 0;
+    const void *fine = a.fine;
 
     // ---- the lane's place: window coordinates (wr, wc) -- any integers, the cell is win_cell0 + wr cols + wc --
     // and the entry of its state.  `fast`: released and beyond its burn-in
@@ -2222,6 +2320,21 @@ __global__ __launch_bounds__(kBlock) void k_step_roam(const StepArgs a, const Th
             if (e == kThrBoundary && !burn) { span = 0u; return; }      // movmodel.py:286-288: the track ends here
             bool exact = true;
             nc = 0;
+            if (fine && !(d1 < d2) && !(burn && ((row <= 1) | (row >= a.rows - 2) | (col >= a.cols - 2)))) {
+                // a near-tie of an ordinary row: the same two boundaries at 32 bits
+                const uint2 f = reinterpret_cast<const uint2 *>(fine)[(cell << 3) | rc];
+                const uint32_t u32 = (w0 & ~31u) | (w1 >> 27);          // top 32 bits of the 53-bit uniform
+                const long long f1 = static_cast<long long>(u32) - static_cast<long long>(f.x);
+                const long long f2 = static_cast<long long>(u32) - static_cast<long long>(f.y);
+                const bool unsure = (f.x > f.y) | (static_cast<unsigned long long>(f1 + 1) < 2ull) | (static_cast<unsigned long long>(f2 + 1) < 2ull);
+                if (!unsure) {
+                    const uint32_t ord = static_cast<uint32_t>(kRingOrder >> (6u * rc)) & 63u;
+                    const uint32_t neg = (f1 < 0 ? 1u : 0u) + (f2 < 0 ? 1u : 0u);
+                    nc = (rc + 7u + ((ord >> (4u - 2u * neg)) & 3u)) & 7u;
+                    exact = false;
+                    ++n_fine;
+                }
+            }
             if (e == kThrReversal && !burn) {
                 // unmasked prior (movmodel.py:239-240): count of thresholds <= u
                 int idx = 0;
@@ -2306,7 +2419,8 @@ __global__ __launch_bounds__(kBlock) void k_step_roam(const StepArgs a, const Th
         // a cell of the raster; one that does not (it stands on a boundary cell, a flag entry, a near-tie)
         // may point up to two rows outside it -- the index is clamped into the table (a negative one wraps to
         // a large unsigned) and the lane looks its state up again below, so what it loads here is never used
-        const int cell_a = win_cell0 + wra * a.cols + wca, cell_b = win_cell0 + wrb * a.cols + wcb;
+        // (24-bit multiplies: |window row| < 2^16 and cols < 2^15; the 32-bit one runs at a quarter of the rate)
+        const int cell_a = win_cell0 + __mul24(wra, a.cols) + wca, cell_b = win_cell0 + __mul24(wrb, a.cols) + wcb;
         {
             const uint32_t cb = static_cast<uint32_t>(cell_b) < last_cell ? static_cast<uint32_t>(cell_b) : last_cell;
             const uint32_t sidx = fast ? ((cb << 3) | ncb) : 0u;
@@ -2355,6 +2469,12 @@ __global__ __launch_bounds__(kBlock) void k_step_roam(const StepArgs a, const Th
         one_pair();
     }
     if (fast) { row = win_r0 + wr; col = win_c0 + wc; }
+    {
+        uint32_t nf = n_fine;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nf += __shfl_down(nf, off);
+        if ((threadIdx.x & 63) == 0 && nf) atomicAdd(&ctl->pad, nf);          // near-ties the fine table settled
+    }
     if ((threadIdx.x & 63) == 0 && n_pairs) {
         atomicAdd(&ctl->roam_pairs, static_cast<unsigned long long>(n_pairs));
         if (n_slow) atomicAdd(&ctl->roam_slow, static_cast<unsigned long long>(n_slow));
@@ -3153,9 +3273,12 @@ __global__ __launch_bounds__(1024) void k_deal_sorted(const uint32_t *__restrict
             int k = 0;
 #pragma unroll
             for (int q = 1; q <= kWanderWindows; ++q) k += off[q] <= g ? 1 : 0;
+            // a thinned block's tracks are dealt over its four waves evenly (slot = wave x 64 + lane <- position
+            // 4 lane + wave): a divergent load takes ~300 clocks plus ~4 per active lane of its wave
             const uint32_t in_run = g - off[k], blk = in_run / kBlock, sl = in_run % kBlock;
-            const uint32_t j = lo[k] + blk * fill + sl;
-            if (sl < fill && j < lo[k + 1]) t = sorted[j];
+            const uint32_t pos = (sl & 63u) * (kBlock / 64u) + (sl >> 6);
+            const uint32_t j = lo[k] + blk * fill + pos;
+            if (pos < fill && j < lo[k + 1]) t = sorted[j];
         }
         // contiguous: list x takes positions [x total / 8, (x + 1) total / 8), whole blocks of ONE window each
         // (total is a multiple of 8 blocks) -- an XCD then steps one or two windows and its L2 holds their
@@ -3339,6 +3462,34 @@ extern "C" int ssrs_build_flags(void)
 #endif
 }
 
+// The masked prior's two boundaries after each last move at 32 bits (k_fine_build's zero rows), by the
+// reference's sequence of movmodel.py:234-244 in f64
+static void fine_prior_tables(const double *prior, FinePrior *out)
+{
+    *out = FinePrior{};
+    for (int rc = 0; rc < 8; ++rc) {
+        const uint32_t mask = restriction(kRingK[rc]);
+        double q[9], qq[9], cdf[9];
+        bool any = false;
+        for (int k = 0; k < 9; ++k) {
+            q[k] = ((mask >> k) & 1u) && k != 4 ? prior[k] : 0.0;
+            any |= q[k] != 0.0;
+        }
+        if (!any) { out->reversal |= 1u << rc; continue; }
+        const double s1 = sum9(q);
+        for (int k = 0; k < 9; ++k) qq[k] = q[k] / s1;
+        const double s2 = sum9(qq);
+        double acc = 0.0;
+        for (int k = 0; k < 9; ++k) { qq[k] = qq[k] / s2; acc = acc + qq[k]; cdf[k] = acc; }
+        const uint32_t ord = ring_order(rc);
+        const int ring3[3] = {(rc + 7) % 8, rc, (rc + 1) % 8};
+        const int ka = kRingK[ring3[ord & 3u]], kb = kRingK[ring3[(ord >> 2) & 3u]];
+        out->zero_t1[rc] = fine_fixed(cdf[ka] / cdf[8]);
+        out->zero_t2[rc] = fine_fixed(cdf[kb] / cdf[8]);
+        if (out->zero_t1[rc] > out->zero_t2[rc]) out->zero_t1[rc] = out->zero_t2[rc];
+    }
+}
+
 extern "C" int ssrs_track_params_init(SsrsTrackParams *p, int rows, int cols,
                                       int memory_parameter, double scaling_parameter)
 {
@@ -3367,7 +3518,8 @@ static size_t pair_table_bytes(int64_t ntracks, int rows, int cols)
 {
     if (ntracks < kWanderMinTracks || rows <= 0 || cols <= 0) return 0;
     const size_t cells = static_cast<size_t>(rows) * static_cast<size_t>(cols);
-    return cells < kPairMaxCells ? align_up(cells * 8 * sizeof(RoamEntry), 256) : 0;
+    // 8 x 16 bytes per cell + the fine table of the near-ties, 8 x 8 bytes per cell
+    return cells < kPairMaxCells ? align_up(cells * 8 * sizeof(RoamEntry), 256) + align_up(cells * 8 * sizeof(FineEntry), 256) : 0;
 }
 
 extern "C" size_t ssrs_tracks_workspace_bytes_ex(int64_t ntracks, int rows, int cols, int hist_copies)
@@ -3651,6 +3803,9 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
         const size_t pb = thr ? pair_table_bytes(ntracks, p->rows, p->cols) : 0;
         if (pb && workspace_bytes >= ws_base + pb) {
             ws.roam = reinterpret_cast<RoamEntry *>(static_cast<char *>(workspace) + ws_base);
+            if (std::getenv("SSRS_TRACKS_NO_FINE_TABLE") == nullptr)          // A/B switch
+                a.fine = static_cast<char *>(workspace) + ws_base +
+                         align_up(static_cast<size_t>(p->rows) * static_cast<size_t>(p->cols) * 8 * sizeof(RoamEntry), 256);
             ws_base += pb;
         }
         a.roam = ws.roam;
@@ -3777,6 +3932,16 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                                              ws.roam, thr_prior);
             else hipLaunchKernelGGL(k_roam_build<false>, dim3(grid), dim3(kBlock), 0, st, tabc, a.guard, a.plane_shift, p->rows, p->cols,
                                     ws.roam, thr_prior);
+            if (a.fine) {
+                FinePrior fp;
+                fine_prior_tables(p->prior, &fp);
+                const int tx = (p->cols + kTabW - 1) / kTabW, ty = (p->rows + kTabH - 1) / kTabH, nt = tx * ty;
+                FineEntry *fine_out = reinterpret_cast<FineEntry *>(const_cast<void *>(a.fine));
+                if (potential) hipLaunchKernelGGL(k_fine_build<true>, dim3(static_cast<unsigned>(nt)), dim3(kBlock), 0, st, updraft, potential,
+                                                  fine_out, p->rows, p->cols, tx, nt, fp);
+                else hipLaunchKernelGGL(k_fine_build<false>, dim3(static_cast<unsigned>(nt)), dim3(kBlock), 0, st, updraft, potential,
+                                        fine_out, p->rows, p->cols, tx, nt, fp);
+            }
             roam_ready = true;
             marks_adjacent = false;
         }
@@ -4146,6 +4311,7 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
         stats->roam_launches = roam_launches;
         stats->roam_wave_pairs = static_cast<int64_t>(host_ctl.roam_pairs);
         stats->roam_slow_wave_pairs = static_cast<int64_t>(host_ctl.roam_slow);
+        stats->reserved0 = static_cast<int32_t>(host_ctl.pad);                   // near-ties settled by the fine table
         // (batches still unexamined when the loop ended: the last one or two of the run)
         stats->block_window_steps = block_window_steps;
         float ms = 0.f;

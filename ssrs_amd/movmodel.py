@@ -346,6 +346,7 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
                            block_window_timed=int(stats.block_window_timed),
                            block_window_steps=int(stats.block_window_steps),
                            roam_launches=int(stats.roam_launches),
+                           roam_fine_settled=int(stats.reserved0),
                            roam_wave_pairs=int(stats.roam_wave_pairs),
                            roam_slow_wave_pairs=int(stats.roam_slow_wave_pairs)))
 

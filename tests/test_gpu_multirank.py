@@ -44,7 +44,7 @@ def _run(world, out_dir, mode):
                 p.wait()
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f'rank {r} failed:\n{o[-3000:]}'
-    return os.path.join(out_dir, f'{mode}_w{world}', 'data', mode)
+    return os.path.join(out_dir, f'{mode}_w{world}', 'data', 'uniform' if mode == 'unseeded' else mode)
 
 
 @pytest.mark.parametrize('mode', ['uniform', 'snapshot', 'seasonal'])
