@@ -29,7 +29,7 @@ _SECTIONS = (
                            'track_dirn_restrict')),
     ('Plotting and wind turbines', ('turbine_minimum_hubheight', 'turbine_mrkr_size',
                                     'fig_height', 'fig_dpi')),
-    ('MI355X build', ('save_tracks', 'stepper_path', 'steps_per_launch')),
+    ('MI355X build', ('save_tracks', 'stepper_path', 'steps_per_launch', 'max_tracks_file_gb', 'hist_safe_tracks')),
 )
 
 
@@ -94,6 +94,9 @@ class Config:
     save_tracks: bool = True            # write <id>_tracks.pkl like the reference
     stepper_path: str = 'auto'          # auto | table | direct
     steps_per_launch: int = 0           # 0 = library default
+    max_tracks_file_gb: float = 64.     # refuse a <id>_tracks.pkl larger than this (tracks that wander to
+    #                                     max_moves: 1 TB per 100k tracks on a solved 10 m field)
+    hist_safe_tracks: int = 200_000     # tracks per uint32 presence histogram; more are added up in 64 bits
 
     def __str__(self):
         known = {f.name for f in fields(self)}

@@ -98,13 +98,19 @@ def reduce_histogram(hist, dst=0, group=None, all_ranks=False, async_op=False, g
     instead of widening, which aborted an 8-GPU run on the solved field by design."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return None if async_op else hist
-    flat = hist.view(torch.int32).reshape(-1)
 
     def run(t, **kw):
         if all_ranks:
             return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, **kw)
         return dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM, group=group, **kw)
 
+    if hist.dtype == torch.int64:
+        # already widened (a rank that stepped its tracks in sub-batches): a plain 64-bit sum
+        if async_op:
+            return _GuardedWork(run(hist.reshape(-1), async_op=True), hist)
+        run(hist.reshape(-1))
+        return hist
+    flat = hist.view(torch.int32).reshape(-1)
     wide = None
     if guard and int(_max_bound(hist, group).item()) >= (1 << 32):
         wide = flat.to(torch.int64) & 0xFFFFFFFF

@@ -174,21 +174,55 @@ def default_record_pool_bytes(n, rows, cols):
 class TrackBatch:
     """Result of simulate_tracks: device tensors + lazy host views."""
 
-    def __init__(self, lengths, ends, hist, traj, offsets, stats):
+    def __init__(self, lengths, ends, hist, traj, offsets, stats, replay=None):
         self.lengths = lengths        # int32 (n)          trajectory points per track
         self.ends = ends              # int16 (n, 2)       last point [row, col]
         self.hist = hist              # uint32-in-int32 (rows, cols) or None
         self.traj = traj              # int16 (sum lengths, 2) or None
         self.offsets = offsets        # int64 (n + 1) or None
         self.stats = stats            # dict(total_steps, launches, kernel_ms, wall_ms)
+        self._replay = replay         # chunked trajectories: callable(t0, t1) -> int16 (points, 2) host array
 
-    def tracks(self):
-        """List[int16 (n_i, 2)] like the reference's pool.map result."""
-        if self.traj is None:
+    @property
+    def total_points(self):
+        """Sum of the trajectory lengths (4 bytes each as int16 pairs)."""
+        return int(self.lengths.sum(dtype=torch.int64).item())
+
+    def iter_tracks(self):
+        """The tracks one by one, int16 (n_i, 2) each, in track order.  When the trajectories did not fit
+        the device budget (Sum lengths x 4 B: 1 TB for 100k tracks on the solved 10 m field, where a
+        third of them take max_moves = 7.5e6) they are produced range by range: the lengths of the
+        finished pass give the ranges, and each range is stepped again with the generic kernel writing
+        every point at its offset (the same counter-based streams: the same tracks)."""
+        if self.traj is not None:
+            traj = self.traj.cpu().numpy()
+            off = self.offsets.cpu().numpy()
+            for i in range(off.size - 1):
+                yield traj[off[i]:off[i + 1]]
+            return
+        if self._replay is None:
             raise ValueError('simulate_tracks was called with want_tracks=False')
-        traj = self.traj.cpu().numpy()
-        off = self.offsets.cpu().numpy()
-        return [traj[off[i]:off[i + 1]] for i in range(off.size - 1)]
+        lengths = self.lengths.cpu().numpy().astype(np.int64)
+        budget_points = max(int(self.stats['traj_chunk_bytes']) // 4, 1)
+        t0, n = 0, lengths.size
+        while t0 < n:
+            t1, pts = t0, 0
+            while t1 < n and (t1 == t0 or pts + lengths[t1] <= budget_points):
+                pts += lengths[t1]
+                t1 += 1
+            traj = self._replay(t0, t1)
+            off = np.concatenate(([0], np.cumsum(lengths[t0:t1])))
+            for i in range(t1 - t0):
+                yield traj[off[i]:off[i + 1]]
+            t0 = t1
+
+    def tracks(self, max_bytes=64 << 30):
+        """List[int16 (n_i, 2)] like the reference's pool.map result (iter_tracks() streams them)."""
+        need = self.total_points * 4
+        if need > max_bytes:
+            raise MemoryError(f'the trajectories of this batch are {need / 2**30:.1f} GiB (Sum lengths x 4 B): '
+                              'stream them with iter_tracks() or run with save_tracks=False')
+        return list(self.iter_tracks())
 
 
 def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
@@ -196,7 +230,7 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
                     seed=0, track_id_base=0, table=None, use_table=None, hist=None,
                     want_hist=True, want_tracks=False, steps_per_launch=0, profile=False,
                     exact_only=False, schedule=True, binning=True, ring=None, scattered=None,
-                    max_moves=None, record=True, record_pool_bytes=None, thr=None):
+                    max_moves=None, record=True, record_pool_bytes=None, thr=None, traj_budget_bytes=None):
     """generate_simulated_tracks for a whole batch (movmodel.py:264-318 under
     simulator.py:360-369) + presence histogram (movmodel.py:410-419).
 
@@ -216,7 +250,9 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
     (ssrs_tracks_simulate_rec + ssrs_tracks_gather): ONE simulation pass on whichever
     stepper path applies.  record=False, or a pool that ran out, takes the two-pass
     form: lengths first, then the same counter-based streams again with the generic
-    kernel writing each point at its final offset.
+    kernel writing each point at its final offset.  When Sum lengths x 4 B exceeds
+    `traj_budget_bytes` (default: a third of the free HBM, at most 16 GiB) no trajectory tensor is
+    allocated at all: TrackBatch.iter_tracks() then steps the batch again range by range.
     """
     rows, cols = int(grid_shape[0]), int(grid_shape[1])
     dev = device()
@@ -283,6 +319,8 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
 
     traj = offsets = None
     recorded = simulated = False
+    if traj_budget_bytes is None:
+        traj_budget_bytes = min(16 << 30, torch.cuda.mem_get_info()[0] // 3)
     if want_tracks and record and n > 0:
         # one pass: every launch's visits stay in the pool, the gather assembles them
         pool_bytes = int(record_pool_bytes) if record_pool_bytes is not None else \
@@ -298,7 +336,8 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
                 C.c_uint64(int(track_id_base)), nat.ptr(hist), nat.ptr(ends),
                 nat.ptr(lengths), C.c_void_p(rec), nat.ptr(ws), C.c_size_t(ws_bytes),
                 C.byref(stats), stream_ptr()))
-            if nat.lib().ssrs_traj_recorder_complete(C.c_void_p(rec)):
+            if nat.lib().ssrs_traj_recorder_complete(C.c_void_p(rec)) and \
+                    int(lengths.sum(dtype=torch.int64).item()) * 4 <= int(traj_budget_bytes):
                 offsets = torch.zeros(n + 1, dtype=torch.int64, device=dev)
                 torch.cumsum(lengths, 0, out=offsets[1:])
                 total = int(offsets[-1].item())
@@ -321,20 +360,47 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
                                   scattered=scattered)
             if max_moves is not None:
                 p.max_moves = int(max_moves)
+    replay = None
     if want_tracks and not recorded:
         # pass 1: lengths only (done already when a recorded run ran out of pool); pass 2
         # replays the same counter-based streams and writes every point at its final
         # offset (no per-track cap).
         if not simulated:
-            run(None, None, None)
+            run(hist, None, None)
         offsets = torch.zeros(n + 1, dtype=torch.int64, device=dev)
         torch.cumsum(lengths, 0, out=offsets[1:])
         total = int(offsets[-1].item())
-        traj = torch.empty((total, 2), dtype=torch.int16, device=dev)
-        run(None if simulated else hist, traj, offsets)
+        if total * 4 <= int(traj_budget_bytes):
+            traj = torch.empty((total, 2), dtype=torch.int16, device=dev)
+            run(None, traj, offsets)
+        else:
+            # too long for one tensor (the reference would hold them as host lists, simulator.py:360-385):
+            # range by range on demand, each range one second pass of its own tracks
+            offsets = None
+            two_table, two_p = table, p
+
+            def replay(t0, t1):
+                sub = st[t0:t1].contiguous()
+                m = t1 - t0
+                sub_len = torch.empty(m, dtype=torch.int32, device=dev)
+                sub_end = torch.empty((m, 2), dtype=torch.int16, device=dev)
+                off = torch.zeros(m + 1, dtype=torch.int64, device=dev)
+                torch.cumsum(lengths[t0:t1], 0, out=off[1:])
+                out = torch.empty((int(off[-1].item()), 2), dtype=torch.int16, device=dev)
+                wsb = nat.lib().ssrs_tracks_workspace_bytes(m)
+                wss = torch.empty(wsb, dtype=torch.uint8, device=dev)
+                st2 = nat.SsrsTrackStats()
+                nat.check(nat.lib().ssrs_tracks_simulate(
+                    C.byref(two_p), nat.ptr(upd), nat.ptr(pot), nat.ptr(two_table), nat.ptr(sub),
+                    C.c_int64(m), C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF),
+                    C.c_uint64(int(track_id_base) + t0), None, nat.ptr(sub_end), nat.ptr(sub_len),
+                    nat.ptr(out), nat.ptr(off), nat.ptr(wss), C.c_size_t(wsb), C.byref(st2), stream_ptr()))
+                if not torch.equal(sub_len, lengths[t0:t1]):
+                    raise RuntimeError('trajectory replay: a track changed its length between the passes')
+                return out.cpu().numpy()
     elif not want_tracks:
         run(hist, None, None)
-    return TrackBatch(lengths, ends, hist, traj, offsets,
+    return TrackBatch(lengths, ends, hist, traj, offsets, replay=replay, stats=
                       dict(total_steps=int(stats.total_steps), launches=int(stats.launches),
                            kernel_ms=float(stats.kernel_ms), wall_ms=float(stats.wall_ms),
                            hist_ms=float(stats.hist_ms), window_launches=int(stats.window_launches),
@@ -342,6 +408,7 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
                            block_window_launches=int(stats.block_window_launches),
                            wander_sorts=int(stats.wander_sorts), timed_launches=int(stats.timed_launches),
                            first_move_ms=float(stats.first_move_ms), recorded=bool(recorded),
+                           traj_chunk_bytes=int(traj_budget_bytes),
                            block_window_ms=float(stats.block_window_ms),
                            block_window_timed=int(stats.block_window_timed),
                            block_window_steps=int(stats.block_window_steps),

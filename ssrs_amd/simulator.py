@@ -472,18 +472,21 @@ class Simulator(Config):
             id_str = self._get_id_string(case_id, real_id)
             start_time = time.time()
             with torch.cuda.stream(torch.cuda.Stream()):
-                batch = movmodel.simulate_tracks(
-                    self.track_direction, my_starts, self.gridsize, self.track_dirn_restrict,
-                    self.track_stochastic_nu, fields[0], fields[1], seed=seed, track_id_base=lo,
-                    use_table=use_table, want_tracks=bool(self.save_tracks),
-                    steps_per_launch=self.steps_per_launch)
-                tracks = batch.tracks() if self.save_tracks else None
+                batch = self._step_case(my_starts, lo, fields, seed, use_table)
                 torch.cuda.current_stream().synchronize()
-            print(f'{id_str}: Simulating {hi - lo} tracks..took {_elapsed(start_time)}',
-                  flush=True)
-            if self.save_tracks:
-                fname = self._get_tracks_fname(case_id, real_id, self.mode_data_dir)
-                self._write_tracks(fname, tracks, sharded)
+                print(f'{id_str}: Simulating {hi - lo} tracks..took {_elapsed(start_time)}',
+                      flush=True)
+                if self.save_tracks:
+                    # (inside the stream's scope: long trajectories are stepped again range by range while written)
+                    need = sum(b.total_points for b in batch.parts) * 4
+                    if need > float(self.max_tracks_file_gb) * 2 ** 30:
+                        raise ValueError(
+                            f'{id_str}: the trajectories of these {hi - lo} tracks are {need / 2 ** 30:.1f} GiB '
+                            f'(Sum lengths x 4 B; max_tracks_file_gb = {self.max_tracks_file_gb:g}): on fields where '
+                            'tracks wander to max_moves run with save_tracks=False, or raise max_tracks_file_gb')
+                    fname = self._get_tracks_fname(case_id, real_id, self.mode_data_dir)
+                    self._write_tracks(fname, (t for b in batch.parts for t in b.iter_tracks()), sharded)
+                    torch.cuda.current_stream().synchronize()
             if sharded:
                 from .distributed import reduce_histogram
                 batch.hist = reduce_histogram(batch.hist, all_ranks=True)
@@ -512,25 +515,93 @@ class Simulator(Config):
                         collect(f.result() for f in done)
                 collect(f.result() for f in pending)
 
+    def _step_case(self, my_starts, lo, fields, seed, use_table):
+        """The tracks of one (case, realisation) on this rank.  The presence histogram is uint32 (the
+        reference's int16 wraps at 32 767, movmodel.py:415): a trap cell of the solved 10 m field takes
+        ~1e9 visits per 100k tracks, so more than `hist_safe_tracks` tracks are stepped in sub-batches whose
+        histograms are added up in 64 bits (K4 takes that form), and every sub-batch is checked by its
+        checksum -- the counts must add up to the points of its tracks; a wrapped cell leaves 2^32 missing."""
+        from .distributed import HistogramOverflow
+        n = int(my_starts.shape[0])
+        step = max(1, int(self.hist_safe_tracks))
+        parts, wide, stats = [], None, None
+        for t0 in range(0, max(n, 1), step):
+            sub = my_starts[t0:t0 + step]
+            b = movmodel.simulate_tracks(
+                self.track_direction, sub, self.gridsize, self.track_dirn_restrict,
+                self.track_stochastic_nu, fields[0], fields[1], seed=seed, track_id_base=lo + t0,
+                use_table=use_table, want_tracks=bool(self.save_tracks),
+                steps_per_launch=self.steps_per_launch)
+            counted = int((b.hist.view(torch.int32).to(torch.int64) & 0xFFFFFFFF).sum().item())
+            if counted != b.total_points:
+                raise HistogramOverflow(
+                    f'presence histogram: {b.total_points - counted} visits are missing from the uint32 counts of '
+                    f'{int(sub.shape[0])} tracks (a cell passed 2^32 - 1): lower Config.hist_safe_tracks '
+                    f'(now {self.hist_safe_tracks})')
+            parts.append(b)
+            if n > step:
+                h64 = b.hist.view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+                wide = h64 if wide is None else wide.add_(h64)
+                b.hist = None
+            if stats is None:
+                stats = dict(b.stats)
+            else:
+                for k, v in b.stats.items():
+                    if isinstance(v, (int, float)) and not isinstance(v, bool):
+                        stats[k] = stats.get(k, 0) + v
+        first = parts[0]
+        out = movmodel.TrackBatch(first.lengths if len(parts) == 1 else torch.cat([b.lengths for b in parts]),
+                                  first.ends if len(parts) == 1 else torch.cat([b.ends for b in parts]),
+                                  first.hist if wide is None else wide, None, None, stats)
+        out.parts = parts
+        return out
+
+    class _TrackStream:
+        """Pickles as a plain list whose items come from an iterator (pickle appends them in batches):
+        <id>_tracks.pkl is written without ever holding all trajectories in memory."""
+
+        def __init__(self, items):
+            self.items = items
+
+        def __reduce__(self):
+            return (list, (), None, iter(self.items))
+
+    @classmethod
+    def _dump_tracks(cls, fobj, tracks):
+        pickler = pickle.Pickler(fobj, protocol=4)
+        pickler.fast = True            # no memo: nothing is shared between tracks, and a memo would keep them all alive
+        pickler.dump(cls._TrackStream(tracks))
+
     def _write_tracks(self, fname, tracks, sharded):
-        """<id>_tracks.pkl (simulator.py:382-385).  Track-sharded runs: every rank writes
-        its share next to it, rank 0 concatenates the shares in rank order (= global track
-        id order) into the one file of the contract and removes them."""
+        """<id>_tracks.pkl (simulator.py:382-385) = pickle of List[int16 (n_i, 2)], written as a stream
+        (`tracks` may be a generator).  Track-sharded runs: every rank writes its share next to it as a
+        sequence of pickled chunks, rank 0 streams the shares in rank order (= global track id order) into
+        the one file of the contract and removes them."""
         if not sharded:
             with open(f'{fname}.pkl', "wb") as fobj:
-                pickle.dump(tracks, fobj)
+                self._dump_tracks(fobj, tracks)
             return
         with open(f'{fname}.pkl.part{self._rank()}', "wb") as fobj:
-            pickle.dump(tracks, fobj)
+            chunk = []
+            for t in tracks:
+                chunk.append(t)
+                if len(chunk) >= 4096:
+                    pickle.dump(chunk, fobj, protocol=4)
+                    chunk = []
+            pickle.dump(chunk, fobj, protocol=4)
         self._barrier()
         if self._rank() == 0:
-            merged = []
-            for r in range(self._world()):
-                with open(f'{fname}.pkl.part{r}', 'rb') as fobj:
-                    merged.extend(pickle.load(fobj))
-                os.remove(f'{fname}.pkl.part{r}')
+            def parts():
+                for r in range(self._world()):
+                    with open(f'{fname}.pkl.part{r}', 'rb') as fobj:
+                        while True:
+                            try:
+                                yield from pickle.load(fobj)
+                            except EOFError:
+                                break
+                    os.remove(f'{fname}.pkl.part{r}')
             with open(f'{fname}.pkl', "wb") as fobj:
-                pickle.dump(merged, fobj)
+                self._dump_tracks(fobj, parts())
         self._barrier()
 
     # ------------------------------------------------------------- presence
