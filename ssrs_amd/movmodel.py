@@ -9,6 +9,8 @@ u(seed, track_id, step) is Philox4x32-10 (include/ssrs_hip.h "Uniform
 contract"), so results do not depend on how tracks are sharded.
 """
 import ctypes as C
+import os
+import threading
 from math import floor, ceil
 
 import numpy as np
@@ -171,6 +173,36 @@ def default_record_pool_bytes(n, rows, cols):
     return int(max(1 << 20, min(want, free // 4))) // 256 * 256
 
 
+# The stepper's scratch is large (8.3 KB per track + the pair / fine tables and histogram copies behind it:
+# 13-15 GB for a million tracks at 5000 x 6000) and lives only for the duration of a call.  Allocating and
+# freeing it around every call left the caching allocator with a freed block of that size which smaller
+# requests of the next pass then split, so that the next 13 GB request went to hipMalloc again (~80 ms,
+# inside somebody's timed region: profiles/r03_notes.md, the 105.8 ms outlier of round 2's 1 M-track
+# sweep).  Each host thread keeps its last workspace per device instead (calls of one thread are serial
+# and return synchronised; Simulator's worker threads each hold their own).
+_ws_local = threading.local()
+
+
+def _workspace(nbytes, dev):
+    if os.environ.get('SSRS_NO_WS_CACHE'):
+        return torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    cache = getattr(_ws_local, 'cache', None)
+    if cache is None:
+        cache = _ws_local.cache = {}
+    key = (dev.type, dev.index)
+    buf = cache.get(key)
+    if buf is None or buf.numel() < nbytes or buf.numel() > 4 * max(nbytes, 1 << 26):
+        cache.pop(key, None)
+        buf = None                                  # (the old block goes back before the new one is asked for)
+        buf = cache[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    return buf[:nbytes]
+
+
+def release_workspaces():
+    """Drop this thread's cached stepper workspaces."""
+    _ws_local.cache = {}
+
+
 class TrackBatch:
     """Result of simulate_tracks: device tensors + lazy host views."""
 
@@ -306,7 +338,7 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
         copies = int(min(64, (4 << 30) // (rows * cols * 4)))
         copies = copies if copies >= 2 else 0
     ws_bytes = nat.lib().ssrs_tracks_workspace_bytes_ex(n, rows, cols, copies)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    ws = _workspace(ws_bytes, dev)
     stats = nat.SsrsTrackStats()
 
     def run(hist_t, traj_t, off_t):

@@ -48,12 +48,17 @@ def test_c1_from_the_dem_with_the_builds_own_fields(gpu, golden):
     # steps on 500 rows), the two direct/iterative solves agree to ~3e-4 (5 f32 ulp; SuperLU
     # itself is only good to that at a condition number of 1e10), so few tracks stay identical
     # and the comparison is statistical: steps per track and the presence map.
-    assert abs(L.mean() / g['lengths'].mean() - 1) < 0.10
+    # The mean of 1000 heavy-tailed lengths (402 .. 20 883 steps) is itself a noisy number: the bound is four
+    # standard errors of the difference of two such means, from the reference's own spread (measured: 3352
+    # against 3060 steps, z = 2.0; profiles/r03_end_to_end_tolerances.txt)
+    se = float(g['lengths'].std(ddof=1)) / np.sqrt(len(L)) * np.sqrt(2.)
+    print(f'steps per track: {L.mean() - 1:.0f} vs {g["lengths"].mean() - 1:.0f}, z = {(L.mean() - g["lengths"].mean()) / se:.2f}')
+    assert abs(L.mean() - g['lengths'].mean()) < 4. * se
     np.save(os.path.join(os.environ.get('GRAFT_REPO_ROOT', '.'), 'gpurun_out', 'c1_hip_potential.npy'), pot) \
         if os.path.isdir(os.path.join(os.environ.get('GRAFT_REPO_ROOT', '.'), 'gpurun_out')) else None
     # K4: smoothed, normalised presence map vs the reference's (strided sample of G8).  The
     # map is a density estimate of 1000 tracks; tracks that diverged land elsewhere, so the
-    # stated tolerance is statistical: mean |d| <= 0.02 and max |d| <= 0.15 of the 0..1 range
+    # stated tolerance is statistical: mean |d| <= 5e-4, max |d| <= 0.10 of the 0..1 range, correlation >= 0.997
     krad = presence.presence_kernel_radius(1000., res, shape)
     assert krad == int(g['krad'])
     sm = presence.smooth_presence_counts(out.hist, krad)
@@ -69,4 +74,5 @@ def test_c1_from_the_dem_with_the_builds_own_fields(gpu, golden):
     same2 = np.mean((out2.lengths.cpu().numpy() == g['lengths']) & (out2.ends.cpu().numpy() == g['ends']).all(1))
     print(f'tracks on K1 orograph + reference potential: identical {same2:.3f}')
     assert same2 >= 0.99          # the <= 1 ulp orograph cells may flip a handful of tracks
-    assert stat[0] <= 0.02 and stat[1] <= 0.15 and stat[2] >= 0.98, stat
+    # about twice what the build shows (mean |d| 2e-4, max |d| 0.047, correlation 0.9985)
+    assert stat[0] <= 5e-4 and stat[1] <= 0.10 and stat[2] >= 0.997, stat

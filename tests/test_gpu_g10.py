@@ -8,6 +8,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+G11_PRESENCE = (2e-4, 0.12, 0.998)        # (mean |d|, max |d|, correlation); measured 6.6e-5, 0.060, 0.99924
 
 
 def _ulp(a, b):
@@ -107,8 +108,8 @@ def test_g10_stepper_on_the_hip_potential(gpu, g10):
     (one differing ulp flips a move and the random stream decides differently from there on),
     and the golden field carries SuperLU's error plus NumPy 2's f32 dead-pair entries (1.5e-4
     together, several f32 ulp at these levels), so no track is expected to stay identical: the
-    comparison is the steps/track distribution (mean within 3 %, maximum within 25 %, quartiles
-    within 5 %) and that nothing wanders."""
+    comparison is the steps/track distribution (mean within 1 %, maximum within 3 %, quartiles
+    within 2 %: about three times what the build shows) and that nothing wanders."""
     from ssrs_amd import layers, movmodel
     from ssrs_amd.potential import solve_potential
     shape = g10['shape']
@@ -120,9 +121,10 @@ def test_g10_stepper_on_the_hip_potential(gpu, g10):
     ref_steps = g10['lengths'] - 1
     q = np.percentile(L - 1, [25, 50, 75]) / np.percentile(ref_steps, [25, 50, 75])
     print(f'steps mean {L.mean() - 1:.0f} vs {ref_steps.mean():.0f}, max {L.max() - 1} vs {ref_steps.max()}, quartile ratios {q}')
-    assert abs((L.mean() - 1) / ref_steps.mean() - 1) < 0.03
-    assert abs((L.max() - 1) / ref_steps.max() - 1) < 0.25
-    assert np.all(np.abs(q - 1) < 0.05)
+    # measured: mean 1060 vs 1059, max 1420 vs 1417, quartile ratios within 0.6 % (profiles/r03_end_to_end_tolerances.txt)
+    assert abs((L.mean() - 1) / ref_steps.mean() - 1) < 0.01
+    assert abs((L.max() - 1) / ref_steps.max() - 1) < 0.03
+    assert np.all(np.abs(q - 1) < 0.02)
     assert L.max() < int(g10['max_moves']) // 100
 
 
@@ -158,12 +160,25 @@ def test_g11_share_of_wandering_tracks_on_the_hip_potential(gpu, g11):
     np.random.seed(30)
     r, c = movmodel.get_starting_indices(2048, (5, 55, 1, 2), 'random', (60., 50.), 50.)
     mm = int(g11['max_moves'])
-    shares = {}
+    shares, maps = {}, {}
+    from ssrs_amd import presence
+    import torch
+    krad = presence.presence_kernel_radius(1000., 50., shape)
     for name, field in (('reference', g11['potential']), ('hip', pot)):
         res = movmodel.simulate_tracks(0., np.stack([r, c], 1), shape, 1, 1., upd, field, seed=30, use_table=True)
         L = res.lengths.cpu().numpy() - 1
         shares[name] = float(np.mean(L >= mm))
         print(f'{name} potential: {shares[name]:.3f} of 2048 tracks stop at max_moves, median of the others '
               f'{np.median(L[L < mm]):.0f} steps')
+        # the smoothed, normalised presence map of these tracks (simulator.py:520-546)
+        acc = torch.zeros(shape, dtype=torch.float64, device='cuda')
+        presence.normalise_add(presence.smooth_presence_counts(res.hist, krad), acc)
+        maps[name] = presence.normalise_to_f32(acc).cpu().numpy().astype(np.float64)
+    dd = np.abs(maps['hip'] - maps['reference'])
+    corr = np.corrcoef(maps['hip'].ravel(), maps['reference'].ravel())[0, 1]
+    print(f'presence map, HIP field against reference field: mean |d| {dd.mean():.2e}, max |d| {dd.max():.4f}, corr {corr:.5f}')
     assert abs(shares['hip'] - shares['reference']) < 0.05
     assert 0.35 < shares['reference'] < 0.6
+    # statistical parity (the tracks differ individually: a track is a chaotic function of the f32 potential);
+    # bounds at about twice what the final build shows (profiles/r03_end_to_end_tolerances.txt)
+    assert dd.mean() <= G11_PRESENCE[0] and dd.max() <= G11_PRESENCE[1] and corr >= G11_PRESENCE[2], (dd.mean(), dd.max(), corr)
