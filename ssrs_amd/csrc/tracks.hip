@@ -431,6 +431,69 @@ __device__ __forceinline__ void window_weights(const double *__restrict__ updraf
     }
 }
 
+// The exact decision at one tenth of the price (round 3).  A near-tie of the 16-bit thresholds sends its lane --
+// and with it its wave -- through window_weights + choose_move: 18 + 26 f64 divisions, ~20 000 clocks for a wave
+// alone on its SIMD, every ~250 wave-steps.  With direction memory 1 only THREE cells are admissible, and when all
+// 18 inputs of the window are finite and moderate (every weight is then finite: no NaN rule, no inf x 0) the
+// reference's sequence reduces to: the three weights in ascending k (same operations as window_weights), clipped
+// at 0 -- their running sums ARE the masked row's cumulative sums bit for bit (the other cells add 0.0) -- decided
+// by choose_three_fast's guarded comparison; all three zero: the masked prior's exact thresholds (k_ctl_init),
+// as k_step_lean does.  7 divisions.  Returns the neighbour index k, or -1: the full sequence decides (inputs not
+// finite or huge, a comparison within 2^-46, the prior picking the centre).
+template <bool HAS_POT>
+__device__ __forceinline__ int exact_three(const double *__restrict__ updraft, const float *__restrict__ potential, int cols,
+                                           int row, int col, uint32_t last_k, const double *__restrict__ thr, double u)
+{
+    const size_t centre = static_cast<size_t>(row) * cols + col;
+    const uint32_t mask = restriction_of(last_k);
+    double v[9];
+    float p[9];
+    bool fine = true;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        v[j] = updraft[centre + dr_of(j) * cols + dc_of(j)];
+        fine &= (v[j] <= 1e150) & (v[j] >= -1e150);                  // (false for NaN)
+        if (HAS_POT) {
+            p[j] = potential[centre + dr_of(j) * cols + dc_of(j)];
+            fine &= fabsf(p[j]) <= 1e38f;
+        }
+    }
+    if (!fine) return -1;
+    const double ic = 1.0 / (v[4] > 1e-06 ? v[4] : 1e-06);
+    double w3[3] = {0.0, 0.0, 0.0};
+    int k3[3] = {0, 0, 0};
+    int n = 0;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        if (j == 4) continue;
+        const bool adm = (mask >> j) & 1u;
+        // (uniform control flow: the division is done for every j of the lane's mask only through the select below)
+        if (adm) {
+            double w = 2.0 / (ic + 1.0 / (v[j] > 1e-06 ? v[j] : 1e-06));      // harmonic mean
+            if (HAS_POT) {
+                const float d = p[4] - p[j];
+                const float ninv = (j & 1) ? 1.f : SSRS_NINV_DIAG;
+                const float e = d * ninv;                                      // stays f32
+                w = w * static_cast<double>(e);
+            }
+            w = w > 0.0 ? w : 0.0;                                             // clip(min=0)
+            if (n == 0) { w3[0] = w; k3[0] = j; } else if (n == 1) { w3[1] = w; k3[1] = j; } else { w3[2] = w; k3[2] = j; }
+            ++n;
+        }
+    }
+    if (n != 3) return -1;
+    if (w3[0] == 0.0 && w3[1] == 0.0 && w3[2] == 0.0) {
+        // every admissible weight is exactly zero: the directional prior decides (movmodel.py:234-240)
+        const double *t = thr + 9u * last_k;
+        int idx = 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) idx += t[k] <= u ? 1 : 0;
+        return (idx == 4 || idx > 8) ? -1 : idx;
+    }
+    const int sel = choose_three_fast(w3[0], w3[1], w3[2], u);
+    return sel < 0 ? -1 : (sel == 0 ? k3[0] : (sel == 1 ? k3[1] : k3[2]));
+}
+
 // ------------------------------------------------------------ transition table
 // One thread per cell: 9+9 cached reads, one 64-B row of 8 f64 written.  Blocks
 // own 64 x 16 cell tiles walked in an XCD-aware order (blocks b and b+8 share an
@@ -568,6 +631,8 @@ struct alignas(16) TrackCtl {
     unsigned long long roam_slow;   // k_step_roam: wave-pairs in which some lane took the slow path
     unsigned long long roam_pairs;  // k_step_roam: wave-pairs run
     unsigned long long dbg_tsum, dbg_tmax, dbg_waves, dbg_slowmax;   // SSRS_TRACKS_DEBUG_ROAM: wave lifetimes of one launch
+    unsigned long long dbg_waits;                                    // same: polls of stepping waves that waited for a staged row
+    unsigned long long dbg_span, dbg_span_max;                       // same: virtual-row span of the blocks of a front (sum << 20 | blocks; max)
 };
 
 static_assert(sizeof(TrackCtl) <= 128 * sizeof(uint32_t), "final read-back slot of pinned_counts()");
@@ -691,6 +756,9 @@ struct StepArgs {
     const WanderWindows *wander; // k_step_thr<6>: the windows of the last wander sort (n = 0: none yet)
     const RoamEntry *roam;       // k_step_roam: the pair table (8 entries per cell of the raster), or NULL
     const void *fine;            // k_step_roam: 32-bit boundaries per (cell, last move) for near-ties, or NULL
+    int ordered;                 // k_step_tracks: block-ordered list reservation (see there)
+    int lr_wait;                 // k_step_thr<.., LR>: waves ahead of the ring wait for their row (SSRS_TRACKS_LDS_ROWS=2)
+    int cheap_exact;             // k_step_thr: near-ties through exact_three first (A/B: SSRS_TRACKS_NO_CHEAP_EXACT)
     int debug_roam;              // k_step_roam: wave lifetimes into the control block (SSRS_TRACKS_DEBUG_ROAM)
     uint32_t vis_r, vis_c;       // visit key = row * vis_r + col * vis_c: (cols, 1), or (1, rows) when
                                  // the front is a column (east / west headings: transposed binning)
@@ -748,6 +816,13 @@ __global__ __launch_bounds__(kBlock) void k_tracks_init(
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
 {
+    // a.ordered: one list reservation per block with its waves in order (the first-move launch of a front whose
+    // later launches stage table rows in LDS: a block's tracks must stay neighbours)
+    __shared__ uint32_t s_cnt[kBlock / 64 + 1];
+    if (a.ordered) {
+        if (threadIdx.x <= kBlock / 64) s_cnt[threadIdx.x] = 0u;
+        __syncthreads();
+    }
     TrackCtl *ctl = a.ctl;
     const int in_slot = a.launch & 3, out_slot = (a.launch + 1) & 3;
     const uint32_t xcd = blockIdx.x % kXcd;
@@ -936,8 +1011,22 @@ __global__ __launch_bounds__(kBlock) void k_step_tracks(const StepArgs a)
     const int lane = lane_id;
     const int nsurv = __popcll(live);
     uint32_t base = 0;
-    if (lane == 0 && nsurv) base = atomicAdd(&ctl->count[out_slot][xcd], static_cast<uint32_t>(nsurv));
-    base = __shfl(base, 0);
+    if (a.ordered) {
+        const int wv = threadIdx.x >> 6;
+        if (lane == 0) s_cnt[wv] = static_cast<uint32_t>(nsurv);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tot = 0;
+            for (int q = 0; q < kBlock / 64; ++q) tot += s_cnt[q];
+            s_cnt[kBlock / 64] = tot ? atomicAdd(&ctl->count[out_slot][xcd], tot) : 0u;
+        }
+        __syncthreads();
+        base = s_cnt[kBlock / 64];
+        for (int q = 0; q < wv; ++q) base += s_cnt[q];
+    } else {
+        if (lane == 0 && nsurv) base = atomicAdd(&ctl->count[out_slot][xcd], static_cast<uint32_t>(nsurv));
+        base = __shfl(base, 0);
+    }
     if (active) {
         const int rank = __popcll(live & ((1ull << lane) - 1ull));
         a.list_out[xcd * a.cap + base + rank] = t;
@@ -992,6 +1081,7 @@ __global__ void k_ctl_init(TrackCtl *ctl, const PriorArg pr, double *__restrict_
         }
         ctl->error = bad; ctl->par_min = 0xFFFFFFFFu; ctl->steps = 0; ctl->strays = 0; ctl->bin_done = 0; ctl->pad = 0; ctl->roam_slow = 0; ctl->roam_pairs = 0;
         ctl->dbg_tsum = ctl->dbg_tmax = ctl->dbg_waves = ctl->dbg_slowmax = 0;
+        ctl->dbg_span = ctl->dbg_span_max = ctl->dbg_waits = 0;
     }
     if (d < 9) ctl->prior[d] = pr.v[d];
     if (d >= 9) return;
@@ -1522,6 +1612,7 @@ struct PfArgs {              // by value: taking the kernel arguments' address w
     long long it_base;
     uint32_t cap;
     int coherent, steps, pf_dir, pf_rc, rows, cols, plane_shift;
+    int debug;
 };
 __device__ __forceinline__ void thr_prefetch_wave(const PfArgs a, uint32_t xcd, uint32_t nlive, const volatile int *s_it)
 {
@@ -1593,17 +1684,190 @@ __device__ __forceinline__ void thr_prefetch_wave(const PfArgs a, uint32_t xcd, 
     if (acc == 0x9E3779B9u && a.steps < 0) a.ctl->pad = 1;      // keeps the loads alive
 }
 
+// LR (round 3): the fifth wave of a front's block STAGES the table rows in LDS instead of pulling them through L2.
+// A north / south front advances a row per iteration, its block's 256 tracks span a few hundred columns, and
+// only the three planes around the heading are read: 16 rows x 3 planes x 384 columns of entries are 72 KB (two
+// blocks per CU).  The staging wave fills a ring of row slots ahead of the slowest stepping wave (each wave
+// publishes its iteration), a slot carries the row it holds as a tag, and a stepping lane reads
+// tag, entry, tag (three LDS reads, ~100 clocks, against 300-600 for the gather through L2): equal tags on both
+// sides of the entry mean the slot was not being rewritten (a wave's LDS operations execute in order, and the
+// staging wave invalidates the tag before it rewrites a slot and sets it after).  Anything else -- another plane,
+// a column outside the window, a row not staged yet or already gone -- is the global gather of before.
+constexpr int kLrRows = 16, kLrCols = 256;          // 48 KB: one dwordx4 wave-load + one ds_write_b128 per row and plane
+// LDS accesses of the ring by address space: a `volatile` generic pointer compiles to flat_load ... sc0 sc1 with a
+// wait after each (measured: the staged variant 2.5x SLOWER than the gather it replaces); these are ds_read / ds_write
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ uint32_t lds_addr(const void *p)
+{
+    return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const lds_u32 *)p));
+}
+__device__ __forceinline__ uint32_t lds_ld(const void *p)
+{
+    return __hip_atomic_load((const lds_u32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_st(void *p, uint32_t v)
+{
+    __hip_atomic_store((lds_u32 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+struct LrShared {
+    int c0, vr_lo, vr_hi, on;          // window origin (even), the block's virtual rows at iteration 0, any live track
+    int tag[kLrRows];                  // row held by each slot, -1: none / being rewritten
+    int itw[kBlock / 64];              // iteration each stepping wave has reached (0x3fffffff: left)
+};
+
+__device__ __forceinline__ void thr_stage_geometry(const PfArgs a, uint32_t xcd, uint32_t nlive, LrShared *g)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t base = (blockIdx.x / kXcd) * kBlock;
+    int vr_lo = 0x7fffffff, vr_hi = -0x7fffffff, c_lo = 0x7fffffff, c_hi = -0x7fffffff;
+    for (int q = 0; q < kBlock / 64; ++q) {
+        const uint32_t il = base + q * 64 + lane;
+        if (il >= nlive) continue;
+        const uint32_t i = xcd * a.cap + il;
+        const int32_t t = a.list_in ? a.list_in[i] : static_cast<int32_t>(i);
+        const TrackState s = a.state[t];
+        if (s.k < 0) continue;
+        const int row = s.pos & 0xFFFF, col = (s.pos >> 16) & 0xFFFF;
+        const long long rel64 = (a.coherent ? static_cast<long long>(s.aux >> 9) : 0) + 1 - a.it_base;
+        const int rel = rel64 > a.steps ? a.steps : (rel64 < 0 ? 0 : static_cast<int>(rel64));
+        const int vr = row - a.pf_dir * rel;              // row at iteration `it` (once released): vr + pf_dir * it
+        vr_lo = vr < vr_lo ? vr : vr_lo;  vr_hi = vr > vr_hi ? vr : vr_hi;
+        c_lo = col < c_lo ? col : c_lo;   c_hi = col > c_hi ? col : c_hi;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        int o = __shfl_xor(vr_lo, off); vr_lo = o < vr_lo ? o : vr_lo;
+        o = __shfl_xor(vr_hi, off); vr_hi = o > vr_hi ? o : vr_hi;
+        o = __shfl_xor(c_lo, off); c_lo = o < c_lo ? o : c_lo;
+        o = __shfl_xor(c_hi, off); c_hi = o > c_hi ? o : c_hi;
+    }
+    if (lane < kLrRows) lds_st(&g->tag[lane], 0xFFFFFFFFu);
+    if (lane < kBlock / 64) lds_st(&g->itw[lane], (base + lane * 64 >= nlive) ? 0x3fffffffu : 0xFFFFFFFFu);     // (waves past the list leave at once)
+    if (lane == 0) {
+        const bool on = vr_lo <= vr_hi;
+        if (a.debug && on) {
+            atomicAdd(&a.ctl->dbg_span, (static_cast<unsigned long long>(vr_hi - vr_lo) << 20) | 1ull);
+            atomicMax(&a.ctl->dbg_span_max, static_cast<unsigned long long>(vr_hi - vr_lo));
+        }
+        if (vr_hi - vr_lo > kLrRows / 2) { if (a.pf_dir > 0) vr_hi = vr_lo + kLrRows / 2; else vr_lo = vr_hi - kLrRows / 2; }   // stragglers fall back
+        int c0 = (c_lo + c_hi + 1 - kLrCols) / 2;                           // window centred on the block's columns
+        const int cmax = a.cols - kLrCols;                                  // (>= 0: host)
+        c0 = c0 < 0 ? 0 : (c0 > cmax ? cmax : c0);
+        lds_st(&g->c0, static_cast<uint32_t>(c0));
+        lds_st(&g->vr_lo, static_cast<uint32_t>(vr_lo));
+        lds_st(&g->vr_hi, static_cast<uint32_t>(vr_hi));
+        lds_st(&g->on, on ? 1u : 0u);
+    }
+}
+
+__device__ __forceinline__ void thr_stage_wave(const PfArgs a, LrShared *g, uint32_t *ring)
+{
+    const int lane = threadIdx.x & 63;
+    if (!lds_ld(&g->on)) return;
+    __builtin_amdgcn_s_setprio(3);                       // ahead of the stepping waves that share its SIMD
+    const int dir = a.pf_dir, c0 = static_cast<int>(lds_ld(&g->c0)), vr_lo = static_cast<int>(lds_ld(&g->vr_lo)),
+              vr_hi = static_cast<int>(lds_ld(&g->vr_hi));
+    const int first = dir > 0 ? vr_lo : vr_hi;           // the row the front needs at iteration 0
+    const char *tab = reinterpret_cast<const char *>(a.table);
+    typedef __attribute__((address_space(1))) const void gmem_t;
+    typedef __attribute__((address_space(3))) void lmem_t;
+    // rows go from global memory straight into the ring (global_load_lds_dwordx4: 64 lanes x 16 bytes = one row of
+    // one plane per instruction, no registers in between), kBatch rows = 6 loads at a time and TWO batches in
+    // flight: a batch's tags are published when the NEXT batch has been issued and `s_waitcnt vmcnt(6)` says the
+    // older six have landed.  Every other LDS access of this loop is inline asm: the compiler orders what it
+    // sees of LDS against outstanding LDS-DMA with vmcnt(0), which would take the second batch out of flight.
+    constexpr int kBatch = 2;
+    static_assert(kLrCols == 256 && kLrRows % kBatch == 0, "64 lanes x 4 entries; a batch never wraps inside itself");
+    int next = first, pend = 0, pend_row = 0;
+    uint32_t n_blocked = 0, n_batches = 0;
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+    const uint32_t itw_addr = lds_addr(&g->itw[0]), tag_addr = lds_addr(&g->tag[0]);
+    auto publish = [&](int row0) {
+        // lanes 0..kBatch-1: tag[slot of row0 + lane] = that row (rows outside the raster keep their -1)
+        const int row = row0 + dir * lane;
+        if (lane < kBatch && row >= 0 && row < a.rows)
+            asm volatile("ds_write_b32 %0, %1" : : "v"(tag_addr + 4u * static_cast<uint32_t>(row & (kLrRows - 1))), "v"(row) : "memory");
+    };
+    for (int spin = 0; spin < (1 << 20); ++spin) {       // (bounded: the stepping waves always leave)
+        int w0, w1, w2, w3;
+        static_assert(kBlock / 64 == 4, "four stepping waves");
+        asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:4\n\tds_read_b32 %2, %4 offset:8\n\t"
+                     "ds_read_b32 %3, %4 offset:12\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3) : "v"(itw_addr) : "memory");
+        int itmin = w0 < w1 ? w0 : w1;
+        itmin = w2 < itmin ? w2 : itmin;
+        itmin = w3 < itmin ? w3 : itmin;
+        itmin = __builtin_amdgcn_readfirstlane(itmin);
+        if (itmin >= 0x3fffffff) break;                   // every stepping wave has left
+        itmin = itmin < 0 ? 0 : itmin;
+        // the slot of row `next` still holds row next -/+ kLrRows, which the slowest wave may need until it has
+        // passed it; and nothing beyond the rows this launch can reach
+        const int ahead = dir * (next - first);           // rows ahead of iteration 0's front
+        if (ahead + kBatch - 1 > itmin + kLrRows - 1 || ahead > a.steps + (vr_hi - vr_lo)) {
+            if (pend) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                publish(pend_row);
+                pend = 0;
+            } else {
+                ++n_blocked;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            continue;
+        }
+        ++n_batches;
+        {   // the batch's slots are in flight from here on
+            const int row = next + dir * lane;
+            if (lane < kBatch)
+                asm volatile("ds_write_b32 %0, %1" : : "v"(tag_addr + 4u * static_cast<uint32_t>(row & (kLrRows - 1))), "v"(-1) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+#pragma unroll
+        for (int q = 0; q < kBatch; ++q) {
+            const int row = next + dir * q, slot = row & (kLrRows - 1);
+            const int rr = row < 0 ? 0 : (row >= a.rows ? a.rows - 1 : row);      // (never published when clamped)
+            const uint32_t cellb = (static_cast<uint32_t>(rr) * static_cast<uint32_t>(a.cols) + static_cast<uint32_t>(c0)) * 4u;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const uint32_t plane = static_cast<uint32_t>((a.pf_rc + 7 + p) & 7) << a.plane_shift;
+                // (4-byte aligned in global memory: row x cols + c0 is any integer)
+                __builtin_amdgcn_global_load_lds((gmem_t *)(tab + (plane + cellb + static_cast<uint32_t>(lane) * 16u)),
+                                                 (lmem_t *)&ring[(slot * 3 + p) * kLrCols], 16, 0, 0);
+            }
+        }
+        if (pend) {
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            static_assert(kBatch * 3 == 6, "the count above");
+            publish(pend_row);
+        }
+        pend = 1;
+        pend_row = next;
+        next += dir * kBatch;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (nothing of this wave is in flight into LDS when it leaves)
+    if (a.debug && lane == 0) {
+        // diagnostics: batches staged, polls that found the ring full, rows staged, the wave's lifetime in clocks
+        atomicAdd(&a.ctl->roam_pairs, (static_cast<unsigned long long>(n_batches) << 32) | n_blocked);
+        atomicAdd(&a.ctl->roam_slow, ((static_cast<unsigned long long>(dir * (next - first)) & 0xFFFFFFFFull) << 32) |
+                                         ((__builtin_amdgcn_s_memtime() - t_begin) >> 8));
+    }
+}
+
 // REV: reversal rows decided in the fast path (ThrPrior::rev_*).  In the basins of a solved field a
 // track falls to the bottom of a pit (a move south, say), finds every way on uphill and the masked
 // prior empty, takes the unmasked prior's move north and falls back: every other step is a reversal,
 // and as a flag entry each one sent its whole wave through the slow path (1030 issue clocks per
 // wave-step against 490 on the ramp).  Three more instructions on the chain: variants without the
 // prefetch wave only.
-template <int HM, bool PF = false, bool REV = false>
+template <int HM, bool PF = false, bool REV = false, bool LR = false>
 __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const StepArgs a, const ThrPrior pr)
 {
     static_assert(!(HM == 6 && PF), "the block window is for batches without a front");
+    static_assert(!LR || (PF && !REV), "staged rows: fronts with a fifth wave");
     __shared__ uint32_t s_win[HM == 6 ? kWinRows * kWinCols : 1];
+    __shared__ __attribute__((aligned(16))) uint32_t s_ring[LR ? kLrRows * 3 * kLrCols : 1];
+    __shared__ LrShared s_lr;
+    __shared__ uint32_t s_cnt[kBlock / 64 + 1];            // LR: survivors per wave (block-ordered list reservation)
+    if (LR && threadIdx.x <= kBlock / 64) s_cnt[threadIdx.x] = 0u;
     __shared__ int s_box[4];
     if (HM == 6) {
         for (int q = threadIdx.x; q < kWinRows * kWinCols; q += kBlock) s_win[q] = 0u;
@@ -1640,12 +1904,14 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
     }
     if (!PF) __syncthreads();
     if (PF) {
+        const PfArgs pa = {a.list_in, a.state, reinterpret_cast<const char *>(a.table) + a.guard, a.ctl, a.it_base, a.cap, a.coherent, a.steps,
+                           a.pf_dir, a.pf_rc, a.rows, a.cols, a.plane_shift, a.debug_roam};
         if (threadIdx.x == 0) s_it = -1;
+        if (LR && threadIdx.x >= kBlock) thr_stage_geometry(pa, xcd, nlive, &s_lr);
         __syncthreads();
         if (threadIdx.x >= kBlock) {
-            const PfArgs pa = {a.list_in, a.state, reinterpret_cast<const char *>(a.table) + a.guard, a.ctl, a.it_base, a.cap, a.coherent, a.steps,
-                               a.pf_dir, a.pf_rc, a.rows, a.cols, a.plane_shift};
-            thr_prefetch_wave(pa, xcd, nlive, &s_it);
+            if (LR) thr_stage_wave(pa, &s_lr, s_ring);
+            else thr_prefetch_wave(pa, xcd, nlive, &s_it);
             return;
         }
     }
@@ -1761,9 +2027,24 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
     if (HM == 3 && a.hist_copies)
         hbase = a.hist_copies + static_cast<size_t>((i >> 6) % static_cast<uint32_t>(a.ncopies)) * static_cast<size_t>(ncell);
     int it = 0;
+    const bool cheap_exact = a.cheap_exact != 0;
+    // LR: row and window column of the cell (the staged rows are addressed by them), the staging wave's window
+    const int lr_c0 = LR ? static_cast<int>(lds_ld(&s_lr.c0)) : 0;
+    const uint32_t lr_h0 = static_cast<uint32_t>(a.pf_rc + 7) & 7u;              // first of the three staged planes
+    int lrow = s.pos & 0xFFFF, lcol = ((s.pos >> 16) & 0xFFFF) - lr_c0;
+    const uint32_t lr_tag0 = lds_addr(s_lr.tag), lr_ring0 = lds_addr(s_ring);   // LDS byte addresses
+    uint32_t lr_miss = 0;                                                       // wave-steps that fell back to the gather
+    uint32_t lr_why[4] = {0u, 0u, 0u, 0u};
+    uint32_t lr_waits = 0;                                                      // polls of a wave that waited for its row
+    auto report = [&](int v) __attribute__((always_inline)) {                   // progress of this wave, for the fifth one
+        if ((threadIdx.x & 63) == 0) {
+            if (LR) lds_st(&s_lr.itw[(threadIdx.x >> 6) & (kBlock / 64 - 1)], static_cast<uint32_t>(v));
+            else atomicMax(&s_it, v);
+        }
+    };
 
     auto one_step = [&](const bool even, const bool burn, const bool publish) __attribute__((always_inline)) {
-        if (PF && publish && even && (it & 7) == 0 && (threadIdx.x & 63) == 0) atomicMax(&s_it, it);
+        if (PF && publish && even && (LR || (it & 7) == 0)) report(it);
         // st: all ones when this lane steps now
         const uint32_t stm = (static_cast<uint32_t>(it - rel) < span) ? 0xFFFFFFFFu : 0u;
         uint32_t w0, w1;
@@ -1797,10 +2078,58 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
             dl = s1 ? la : dl;  pl = s1 ? pa : pl;
             dl = stm ? dl : 0u; pl = stm ? pl : pcur;
             cell_n = cell + dl;
-            e_n = *reinterpret_cast<const uint32_t *>(tab + (pl + (cell_n << 2)));
-            // which one it was (off the chain)
+            // which one it was (off the chain; LR: on it)
             const uint32_t fld = (lpk >> (s1 ? 0u : (s2 ? 8u : 16u))) & 0xFFu;
             nc = fld & 7u; dr = (fld >> 3) & 3u; dc = (fld >> 5) & 3u;
+            if (!LR) {
+                e_n = *reinterpret_cast<const uint32_t *>(tab + (pl + (cell_n << 2)));
+            } else {
+                // the entry of the cell the move leads to, from the staged rows: tag, entry, tag (in this order)
+                const int row_n = lrow + static_cast<int>((dr - 1u) & stm), col_n = lcol + static_cast<int>((dc - 1u) & stm);
+                const uint32_t pidx = ((stm ? nc : rc) - lr_h0) & 7u;
+                const uint32_t slot = static_cast<uint32_t>(row_n) & (kLrRows - 1);
+                const bool ok = (pidx < 3u) & (static_cast<uint32_t>(col_n) < static_cast<uint32_t>(kLrCols));
+                const uint32_t idx = ok ? (slot * 3u + pidx) * kLrCols + static_cast<uint32_t>(col_n) : 0u;
+                uint32_t t1, el, t2;
+                {
+                    const uint32_t ta = lr_tag0 + (slot << 2), ea = lr_ring0 + (idx << 2);
+                    asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %4\n\tds_read_b32 %2, %3\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(t1), "=&v"(el), "=&v"(t2) : "v"(ta), "v"(ea) : "memory");
+                }
+                bool need = (stm != 0u) & !(ok & (static_cast<int>(t1) == row_n) & (static_cast<int>(t2) == row_n));
+                e_n = stm ? el : e;                                    // (a lane that does not step keeps its entry)
+                if (__builtin_expect(__any(need), 0)) {
+                    // A row that is not there YET (slot empty or still holding the row of a ring turn before): this
+                    // wave is ahead of the block's slowest one by most of the ring.  It waits for the staging wave
+                    // instead of overtaking it with gathers -- the block ends with its slowest wave either way, and
+                    // waves that run apart find nothing staged from then on (measured: the waves of a block
+                    // diffuse apart through their exact decisions until the leaders ride the ring's edge, 68 % of
+                    // the wave-steps fell back).  Bounded: the slowest wave never waits, so the staging wave
+                    // always gets here; a row this launch never stages is gathered after the last poll.
+                    const int dirw = a.pf_dir;
+                    bool wait = need & ok & ((static_cast<int>(t1) < 0) | (dirw * (static_cast<int>(t1) - row_n) < 0));
+                    for (int sp = 0; a.lr_wait && sp < 256 && __any(wait); ++sp) {
+                        __builtin_amdgcn_s_sleep(2);
+                        const uint32_t ta = lr_tag0 + (slot << 2), ea = lr_ring0 + (idx << 2);
+                        asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %4\n\tds_read_b32 %2, %3\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=&v"(t1), "=&v"(el), "=&v"(t2) : "v"(ta), "v"(ea) : "memory");
+                        const bool hit = (static_cast<int>(t1) == row_n) & (static_cast<int>(t2) == row_n);
+                        if (wait & hit) { e_n = el; need = false; }
+                        wait = wait & !hit & ((static_cast<int>(t1) < 0) | (dirw * (static_cast<int>(t1) - row_n) < 0));
+                        if (a.debug_roam) ++lr_waits;
+                    }
+                }
+                if (__builtin_expect(__any(need), 0)) {
+                    if (need) e_n = *reinterpret_cast<const uint32_t *>(tab + (pl + (cell_n << 2)));
+                    ++lr_miss;
+                    if (a.debug_roam) {       // which kind (lane-steps): window / plane, slot empty, slot holds an older row, a newer one
+                        lr_why[0] += (need && !ok) ? 1u : 0u;
+                        lr_why[1] += (need && ok && static_cast<int>(t1) < 0) ? 1u : 0u;
+                        lr_why[2] += (need && ok && static_cast<int>(t1) >= 0 && static_cast<int>(t1) < row_n) ? 1u : 0u;
+                        lr_why[3] += (need && pidx >= 3u) ? 1u : 0u;          // (of the first kind: the plane)
+                    }
+                }
+            }
         } else {
             // a reversal row is an ordinary row of the move along the heading with the prior's thresholds
             const bool rev = e == kThrReversal;
@@ -1819,6 +2148,7 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
         }
         special = special & (stm != 0u);
         uint32_t base = cell, base_col = colv;
+        int base_row = 0;
         const uint32_t cell_before = cell;
         uint32_t go = stm;
         if (__builtin_expect(__any(special), 0)) {
@@ -1851,17 +2181,24 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
                         if (er <= 1) er += 2; else if (er >= a.rows - 2) er -= 2;
                         if (ec <= 0) ec += 2; else if (ec >= a.cols - 2) ec -= 2;
                     }
-                    double w[9];
-                    if (a.potential) window_weights<true>(a.updraft, a.potential, a.cols, er, ec, w);
-                    else window_weights<false>(a.updraft, a.potential, a.cols, er, ec, w);
-                    double prr[9];
-#pragma unroll
-                    for (int j = 0; j < 9; ++j) prr[j] = a.prior[j];
                     const uint32_t last = static_cast<uint32_t>(kKOfRing >> (4 * rc)) & 0xFu;
-                    const int idx = choose_move(w, prr, 1.0, restriction_of(last), words_to_uniform(w0, w1), false);
+                    const double uu = words_to_uniform(w0, w1);
+                    int idx = -1;
+                    if (cheap_exact) idx = a.potential ? exact_three<true>(a.updraft, a.potential, a.cols, er, ec, last, a.thr, uu)
+                                                       : exact_three<false>(a.updraft, a.potential, a.cols, er, ec, last, a.thr, uu);
+                    if (idx < 0) {
+                        double w[9];
+                        if (a.potential) window_weights<true>(a.updraft, a.potential, a.cols, er, ec, w);
+                        else window_weights<false>(a.updraft, a.potential, a.cols, er, ec, w);
+                        double prr[9];
+#pragma unroll
+                        for (int j = 0; j < 9; ++j) prr[j] = a.prior[j];
+                        idx = choose_move(w, prr, 1.0, restriction_of(last), uu, false);
+                    }
                     nc = static_cast<uint32_t>(kRingOfK >> (4 * idx)) & 0xFu;
                     base = __umul24(static_cast<uint32_t>(er), ucols) + static_cast<uint32_t>(ec);
                     base_col = static_cast<uint32_t>(ec);
+                    base_row = er;
                     if (HM == 6) { wr += er - static_cast<int>(r); wc += ec - static_cast<int>(c); }      // the nudge
                 }
             }
@@ -1896,6 +2233,13 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
             // column of the new cell (the exact path may have moved the base: recompute there)
             const uint32_t moved_col = base == cell_before ? colv + dc - 1u : base_col + dc - 1u;
             colv = (moved_col & go) | (colv & ~go);
+        }
+        if (LR) {
+            // (base_col is only meaningful where the exact path set it: base != cell_before)
+            const int nr = (base == cell_before ? lrow : base_row) + static_cast<int>(dr) - 1;
+            const int ncl = (base == cell_before ? lcol : static_cast<int>(base_col) - lr_c0) + static_cast<int>(dc) - 1;
+            lrow = go ? nr : lrow;
+            lcol = go ? ncl : lcol;
         }
         e = e_n;
         if (!arith) {
@@ -1947,9 +2291,10 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
     // backward branch instead of four of each (a wave pays 25-40 clocks per branch, taken or not)
     for (; it + 8 <= a.steps; ) {
         if (!__any(static_cast<uint32_t>(it - rel) < span || (it < rel && span != 0u))) break;
-        if (PF && (threadIdx.x & 63) == 0) atomicMax(&s_it, it);
+        if (PF) report(it);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
+            if (LR && u == 2) report(it);                  // (the staging wave looks at the slowest wave: every four iterations)
             one_step(true, false, false);
             one_step(false, false, false);
         }
@@ -1969,7 +2314,17 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
             *vrow16 = 0xFFFFu;
             vrow16 += a.visit_stride;
         }
-    if (PF && (threadIdx.x & 63) == 0) atomicMax(&s_it, 0x3fffffff);   // nothing left to wait for
+    if (PF) report(0x3fffffff);                                        // nothing left to wait for
+    if (LR && a.debug_roam) {
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&ctl->dbg_tsum, static_cast<unsigned long long>(lr_miss));
+            atomicAdd(&ctl->dbg_waves, static_cast<unsigned long long>(it));
+            atomicAdd(&ctl->dbg_waits, static_cast<unsigned long long>(lr_waits));
+        }
+        // (lane-steps by kind, packed: 16 bits of millions would overflow: two 64-bit words, 32 bits each)
+        atomicAdd(&ctl->dbg_tmax, (static_cast<unsigned long long>(lr_why[0]) << 32) | lr_why[1]);
+        atomicAdd(&ctl->dbg_slowmax, (static_cast<unsigned long long>(lr_why[2]) << 32) | lr_why[3]);
+    }
     if (HM == 6) {
         __syncthreads();
         for (int q = threadIdx.x; q < kWinRows * kWinCols; q += kBlock) {
@@ -2024,6 +2379,23 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
                 a.state[t] = o;
             }
         }
+    } else if (LR) {
+        // one reservation per block, its waves in order: the block's tracks stay neighbours in the next list
+        // (per-wave reservations land in arrival order and scatter a block over its XCD's band of columns --
+        // harmless for gathers through L2, fatal for a 256-column window in LDS: a third of the lane-steps fell
+        // outside it).  The waves past the list and the staging wave have left; a barrier counts the waves
+        // that are still there.
+        const int wv = threadIdx.x >> 6;
+        if (lane == 0) s_cnt[wv] = static_cast<uint32_t>(nsurv);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tot = 0;
+            for (int q = 0; q < kBlock / 64; ++q) tot += s_cnt[q];
+            s_cnt[kBlock / 64] = tot ? atomicAdd(&ctl->count[out_slot][xcd], tot) : 0u;
+        }
+        __syncthreads();
+        basei = s_cnt[kBlock / 64];
+        for (int q = 0; q < wv; ++q) basei += s_cnt[q];
     } else {
         if (lane == 0 && nsurv) basei = atomicAdd(&ctl->count[out_slot][xcd], static_cast<uint32_t>(nsurv));
         basei = __shfl(basei, 0);
@@ -3736,6 +4108,7 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
     a.thr = ws.thr;
     a.wander = ws.wander;
     a.debug_roam = std::getenv("SSRS_TRACKS_DEBUG_ROAM") != nullptr ? 1 : 0;
+    a.cheap_exact = std::getenv("SSRS_TRACKS_NO_CHEAP_EXACT") == nullptr ? 1 : 0;
     a.vcap = ws.cap;
     const bool lean = p->memory_parameter == 1 && traj == nullptr;
     const bool ring = (p->flags & SSRS_TRACKS_RING_TABLE) != 0;
@@ -3814,6 +4187,12 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
     const bool roam_ok = cache_ok && ws.roam != nullptr && std::getenv("SSRS_TRACKS_NO_ROAM_TABLE") == nullptr;
     const bool roam_rev = thr_prior.rev_ok != 0 && std::getenv("SSRS_TRACKS_NO_REV") == nullptr;
     const bool deal_contiguous = std::getenv("SSRS_TRACKS_DEAL_ROUND_ROBIN") == nullptr;
+    // LDS-staged table rows for fronts (k_step_thr<.., LR = true>): built and parity-tested, measured SLOWER than the
+    // gather behind the prefetch wave (profiles/r03_notes.md section 7), so it is off unless asked for
+    // (=2: waves that are ahead of the ring wait for their row instead of gathering it -- slower still)
+    const char *lds_rows_env = std::getenv("SSRS_TRACKS_LDS_ROWS");
+    const bool lds_rows = lds_rows_env != nullptr;
+    a.lr_wait = (lds_rows && std::atoi(lds_rows_env) == 2) ? 1 : 0;
     bool roam_ready = false;
     int roam_launches = 0, stable_roam = 0;
     int roam_steps = 128 * S;                // A/B: SSRS_TRACKS_ROAM_STEPS (4096: 0.0073, 16384: 0.0060, 65536: 0.0053 ns per step at C2)
@@ -3996,6 +4375,7 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                         binning_on ? 1 : 0, tiles_on ? 1 : 0, scattered ? 1 : 0, cached ? 1 : 0, ws.cap);
             a.steps = Sl;
             a.coherent = (coherent && !first_move) ? 1 : 0;
+            a.ordered = (first_move && a.pf_dir != 0 && lds_rows && p->cols >= kLrCols) ? 1 : 0;
             a.it_base = thr && launch > 0 ? it_done : 0;
             a.visits = nullptr;
             if (!binning_on && scattered && copies_ptr && !copies_live && !cached) {
@@ -4066,8 +4446,11 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                     // outgrown the row window (tile buckets) it streams rows nobody reads: 7.40 -> 7.06 s
                     // per 100k tracks on the solved 10 m field without it
                     const bool pf = a.pf_dir != 0 && a.coherent && !scattered && !tiles_on;
+                    // (staged rows: opt-in switch SSRS_TRACKS_LDS_ROWS; the window is kLrCols wide)
+                    const bool lr = pf && p->cols >= kLrCols && lds_rows;
                     if (v16) {
-                        hipLaunchKernelGGL((k_step_thr<4, true>), dim3(blocks), dim3(kBlock + 64), 0, st, a, thr_prior);
+                        if (lr) hipLaunchKernelGGL((k_step_thr<4, true, false, true>), dim3(blocks), dim3(kBlock + 64), 0, st, a, thr_prior);
+                        else hipLaunchKernelGGL((k_step_thr<4, true>), dim3(blocks), dim3(kBlock + 64), 0, st, a, thr_prior);
                         break;
                     }
                     const bool rev = thr_prior.rev_ok != 0 && std::getenv("SSRS_TRACKS_NO_REV") == nullptr;
@@ -4097,6 +4480,7 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                         break;
                     }
                     if (a.visits && hist_t && binning_on) hipLaunchKernelGGL((k_step_thr<2>), dim3(blocks), dim3(kBlock), 0, st, a, thr_prior);
+                    else if (a.visits && lr) hipLaunchKernelGGL((k_step_thr<1, true, false, true>), dim3(blocks), dim3(kBlock + 64), 0, st, a, thr_prior);
                     else if (a.visits && pf) hipLaunchKernelGGL((k_step_thr<1, true>), dim3(blocks), dim3(kBlock + 64), 0, st, a, thr_prior);
                     else if (a.visits && rev) hipLaunchKernelGGL((k_step_thr<1, false, true>), dim3(blocks), dim3(kBlock), 0, st, a, thr_prior);
                     else if (a.visits) hipLaunchKernelGGL((k_step_thr<1>), dim3(blocks), dim3(kBlock), 0, st, a, thr_prior);
@@ -4301,6 +4685,20 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
     } else {
         (void)hipStreamSynchronize(st);
     }
+    if (a.debug_roam && rc == SSRS_OK && roam_launches == 0 && host_ctl.dbg_waves)
+        fprintf(stderr, "[front] staged rows: %llu wave-steps, %llu of them fell back to the gather (%.4f); lane-steps: outside window / plane %llu, "
+                        "slot empty %llu, slot holds another row %llu; outside by its plane (of the first) %llu\n", host_ctl.dbg_waves,
+                host_ctl.dbg_tsum, static_cast<double>(host_ctl.dbg_tsum) / static_cast<double>(host_ctl.dbg_waves),
+                host_ctl.dbg_tmax >> 32, host_ctl.dbg_tmax & 0xFFFFFFFFull, host_ctl.dbg_slowmax >> 32, host_ctl.dbg_slowmax & 0xFFFFFFFFull);
+    if (a.debug_roam && rc == SSRS_OK && roam_launches == 0 && host_ctl.roam_pairs)
+        fprintf(stderr, "[front] staging waves: %llu batches, %llu polls that found the ring full, %llu rows, %.3e clocks of lifetime in all\n",
+                host_ctl.roam_pairs >> 32, host_ctl.roam_pairs & 0xFFFFFFFFull, host_ctl.roam_slow >> 32,
+                static_cast<double>(host_ctl.roam_slow & 0xFFFFFFFFull) * 256.0);
+    if (a.debug_roam && rc == SSRS_OK && roam_launches == 0 && (host_ctl.dbg_span & 0xFFFFFull))
+        fprintf(stderr, "[front] rows between the first and the last track of a block's front (by the row each would be on at iteration 0): "
+                        "mean %.1f over %llu blocks, max %llu; the ring holds %d; %llu polls of stepping waves that waited for their row\n",
+                static_cast<double>(host_ctl.dbg_span >> 20) / static_cast<double>(host_ctl.dbg_span & 0xFFFFFull),
+                host_ctl.dbg_span & 0xFFFFFull, host_ctl.dbg_span_max, kLrRows, host_ctl.dbg_waits);
     if (stats && rc == SSRS_OK) {
         stats->total_steps = static_cast<int64_t>(host_ctl.steps);
         stats->launches = launch;

@@ -779,6 +779,43 @@ def test_thr_table_large_batch_equals_f64_table(gpu):
         assert int(b[2].sum()) == int(b[0].sum())
 
 
+@pytest.mark.parametrize('dirn', [0., 180.])
+def test_front_kernel_variants_give_the_oracles_integers(gpu, dirn):
+    """North / south fronts on a raster at least 256 columns wide, through the variants of the front kernel
+    behind their switches: SSRS_TRACKS_LDS_ROWS (table rows staged in LDS by a fifth wave with
+    global_load_lds, read through a tag / entry / tag sequence; opt-in: measured slower than the gather,
+    profiles/r03_notes.md section 7) and SSRS_TRACKS_NO_CHEAP_EXACT (near-ties straight to the full exact
+    sequence instead of the seven-division decision).  Same lengths, ends and histogram as the C oracle."""
+    import os
+    from ssrs_amd import movmodel
+    from oracle import c_oracle
+    rows, cols = 700, 520
+    upd, _ = _random_field_case(rows, cols, 52)
+    rng = np.random.default_rng(21)
+    rr = np.arange(rows, dtype=np.float64)[:, None]
+    along = rr if dirn == 0. else (rows - 1 - rr)
+    pot = (1000. * (1 - along / (rows - 1)) + rng.normal(0, 0.05, (rows, cols))).astype(np.float32)
+    n = 12000
+    t = rng.integers(2, 30, n)
+    starts = np.stack([t if dirn == 0. else rows - 1 - t, rng.integers(0, cols, n)], 1)
+    ref = c_oracle.simulate_tracks(dirn, starts, (rows, cols), 1, 1., upd, pot, seed=17, want_traj=False)
+    for switch, value in ((None, ''), ('SSRS_TRACKS_LDS_ROWS', '1'), ('SSRS_TRACKS_LDS_ROWS', '2'),
+                          ('SSRS_TRACKS_NO_CHEAP_EXACT', '1')):
+        if switch:
+            os.environ[switch] = value
+        try:
+            res = movmodel.simulate_tracks(dirn, starts, (rows, cols), 1, 1., upd, pot, seed=17, use_table=True,
+                                           thr=True)
+        finally:
+            if switch:
+                del os.environ[switch]
+        lens, ends, hist = _no_traj_result(res)
+        assert res.stats['window_launches'] > 0, switch
+        assert np.array_equal(lens, ref['lengths']), (dirn, switch)
+        assert np.array_equal(ends, ref['ends']), (dirn, switch)
+        assert np.array_equal(hist, ref['hist']), (dirn, switch)
+
+
 def test_thr_table_belongs_to_one_heading(gpu):
     from ssrs_amd import movmodel
     upd, pot = _random_field_case(40, 50, 1)
