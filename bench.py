@@ -47,7 +47,7 @@ RASTER_BYTES_PER_CELL = 20      # fused K1 as benchmarked: f64 DEM in (8) + f32 
 # Roaming batches (k_step_roam, one block of 144 KB LDS per CU): every CU holding a FULL block of 256 tracks
 # (profiles/r03_roam_fill.txt)
 THROUGHPUT_BOUND_STEPS_PER_S = 2.0e11
-ROAM_THROUGHPUT_BOUND_STEPS_PER_S = 2.9e11
+ROAM_THROUGHPUT_BOUND_STEPS_PER_S = 2.1e11
 
 
 def parse():
@@ -369,11 +369,16 @@ def attach_traffic(roof, variant_ok):
     try:
         with open(pmc) as f:
             rec = json.load(f)
-        key = 'solved' if '<6' in roof['kernel'] else 'ramp'
-        ent = rec.get(key)
-        if ent:
-            roof['traffic'] = ent.get('bytes_per_launch')
-            roof['traffic_source'] = 'profile constant (not counted in this run): ' + str(ent.get('source'))
+        # {"solved": <summarize_pmc.py record of a solved-field pass>, "ramp": <... of the stand-in>}
+        solved = 'k_step_roam' in roof['kernel'] or '<6' in roof['kernel']
+        ent = rec.get('solved' if solved else 'ramp') or {}
+        want = 'k_step_roam' if 'k_step_roam' in roof['kernel'] else ('k_step_thr<6' if solved else 'k_step_thr<4')
+        for kname, k in (ent.get('kernels') or {}).items():
+            if want in kname:
+                roof['traffic'] = k.get('corrected_bytes')
+                roof['traffic_kernel'] = kname
+                roof['traffic_source'] = 'profile constant (not counted in this run): ' + str(ent.get('source'))
+                break
     except Exception:
         pass
 

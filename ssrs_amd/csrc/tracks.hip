@@ -212,6 +212,30 @@ __device__ __forceinline__ uint4 philox_block(uint64_t seed, uint64_t track, uin
     return rocrand4(&st);
 }
 
+// The same block with the ten rounds written out for gfx950: a round's two three-input xors (product high word ^
+// counter word ^ round key) are ONE v_bitop3_b32 each (truth table 0x96) where the compiler makes two v_xor_b32 of
+// rocRAND's source -- 17 of the 155 vector instructions of a pair of moves in k_step_roam.  Counter and key as
+// rocrand_init(seed, subsequence = track, offset = 4 blk) sets them; k_uniform_selftest compares the two word for word.
+__device__ __forceinline__ uint4 philox_block_b3(uint64_t seed, uint64_t track, uint64_t blk)
+{
+    uint32_t c0 = static_cast<uint32_t>(blk), c1 = static_cast<uint32_t>(blk >> 32);
+    uint32_t c2 = static_cast<uint32_t>(track), c3 = static_cast<uint32_t>(track >> 32);
+    uint32_t k0 = static_cast<uint32_t>(seed), k1 = static_cast<uint32_t>(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = static_cast<uint64_t>(0xD2511F53u) * c0, p1 = static_cast<uint64_t>(0xCD9E8D57u) * c2;
+        const uint32_t n0 = __builtin_amdgcn_bitop3_b32(static_cast<uint32_t>(p1 >> 32), c1, k0, 0x96);
+        const uint32_t n2 = __builtin_amdgcn_bitop3_b32(static_cast<uint32_t>(p0 >> 32), c3, k1, 0x96);
+        c1 = static_cast<uint32_t>(p1);
+        c3 = static_cast<uint32_t>(p0);
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+
 __device__ __forceinline__ double words_to_uniform(uint32_t a, uint32_t b)
 {   // numpy legacy random_sample: 53 bits, [0, 1)
     return (static_cast<double>(a >> 5) * 67108864.0 + static_cast<double>(b >> 6)) *
@@ -224,7 +248,10 @@ __global__ void k_uniform_selftest(uint64_t seed, const uint64_t *track, const u
     const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
     if (i >= n) return;
     const uint4 w = philox_block(seed, track[i], step[i] >> 1);
-    out[i] = (step[i] & 1) ? words_to_uniform(w.z, w.w) : words_to_uniform(w.x, w.y);
+    const uint4 v = philox_block_b3(seed, track[i], step[i] >> 1);
+    const bool same = w.x == v.x && w.y == v.y && w.z == v.z && w.w == v.w;          // rocRAND's engine and the written-out rounds
+    const double u = (step[i] & 1) ? words_to_uniform(w.z, w.w) : words_to_uniform(w.x, w.y);
+    out[i] = same ? u : __longlong_as_double(0x7FF8000000000000ll);
 }
 
 // ------------------------------------------------------------ move decision
@@ -631,6 +658,7 @@ struct alignas(16) TrackCtl {
     unsigned long long roam_slow;   // k_step_roam: wave-pairs in which some lane took the slow path
     unsigned long long roam_pairs;  // k_step_roam: wave-pairs run
     unsigned long long dbg_tsum, dbg_tmax, dbg_waves, dbg_slowmax;   // SSRS_TRACKS_DEBUG_ROAM: wave lifetimes of one launch
+    uint32_t roam_stop, roam_stop_pad;                               // k_step_roam: launch + 1 of the launch whose first wave is through its steps
     unsigned long long dbg_waits;                                    // same: polls of stepping waves that waited for a staged row
     unsigned long long dbg_span, dbg_span_max;                       // same: virtual-row span of the blocks of a front (sum << 20 | blocks; max)
 };
@@ -757,8 +785,10 @@ struct StepArgs {
     const RoamEntry *roam;       // k_step_roam: the pair table (8 entries per cell of the raster), or NULL
     const void *fine;            // k_step_roam: 32-bit boundaries per (cell, last move) for near-ties, or NULL
     int ordered;                 // k_step_tracks: block-ordered list reservation (see there)
+    int roam_stop;               // k_step_roam: a launch ends when its FIRST wave is through its steps (A/B: SSRS_TRACKS_NO_ROAM_STOP)
     int lr_wait;                 // k_step_thr<.., LR>: waves ahead of the ring wait for their row (SSRS_TRACKS_LDS_ROWS=2)
     int cheap_exact;             // k_step_thr: near-ties through exact_three first (A/B: SSRS_TRACKS_NO_CHEAP_EXACT)
+    unsigned long long *dbg_buf; // diagnostic builds (SSRS_DEBUG_WAVE_DUMP): one record per wave
     int debug_roam;              // k_step_roam: wave lifetimes into the control block (SSRS_TRACKS_DEBUG_ROAM)
     uint32_t vis_r, vis_c;       // visit key = row * vis_r + col * vis_c: (cols, 1), or (1, rows) when
                                  // the front is a column (east / west headings: transposed binning)
@@ -1082,6 +1112,7 @@ __global__ void k_ctl_init(TrackCtl *ctl, const PriorArg pr, double *__restrict_
         ctl->error = bad; ctl->par_min = 0xFFFFFFFFu; ctl->steps = 0; ctl->strays = 0; ctl->bin_done = 0; ctl->pad = 0; ctl->roam_slow = 0; ctl->roam_pairs = 0;
         ctl->dbg_tsum = ctl->dbg_tmax = ctl->dbg_waves = ctl->dbg_slowmax = 0;
         ctl->dbg_span = ctl->dbg_span_max = ctl->dbg_waits = 0;
+        ctl->roam_stop = ctl->roam_stop_pad = 0;
     }
     if (d < 9) ctl->prior[d] = pr.v[d];
     if (d >= 9) return;
@@ -2049,7 +2080,7 @@ __global__ __launch_bounds__(PF ? kBlock + 64 : kBlock) void k_step_thr(const St
         const uint32_t stm = (static_cast<uint32_t>(it - rel) < span) ? 0xFFFFFFFFu : 0u;
         uint32_t w0, w1;
         if (even) {
-            const uint4 w4 = philox_block(a.seed, track, static_cast<unsigned long long>(static_cast<uint32_t>(blk0 + (it >> 1))));
+            const uint4 w4 = philox_block_b3(a.seed, track, static_cast<unsigned long long>(static_cast<uint32_t>(blk0 + (it >> 1))));
             w0 = w4.x; w1 = w4.y; pend_a = w4.z; pend_b = w4.w;
         } else {
             w0 = pend_a; w1 = pend_b;
@@ -2759,7 +2790,7 @@ __global__ __launch_bounds__(kBlock) void k_step_roam(const StepArgs a, const Th
     uint32_t n_pairs = 0, n_slow = 0;                         // wave-uniform
     const unsigned long long t_begin = a.debug_roam ? __builtin_amdgcn_s_memtime() : 0ull;
     auto one_pair = [&]() __attribute__((always_inline)) {
-        const uint4 w4 = philox_block(a.seed, track, static_cast<unsigned long long>(static_cast<uint32_t>(blk0 + (it >> 1))));
+        const uint4 w4 = philox_block_b3(a.seed, track, static_cast<unsigned long long>(static_cast<uint32_t>(blk0 + (it >> 1))));
         const uint32_t ufa = w4.x >> 16, ufb = w4.z >> 16;
         const bool st_a = static_cast<uint32_t>(it - rel) < span, st_b = static_cast<uint32_t>(it + 1 - rel) < span;
         // (copies into locals before any select: see k_step_thr on selects of captured variables)
@@ -2831,15 +2862,30 @@ __global__ __launch_bounds__(kBlock) void k_step_roam(const StepArgs a, const Th
         }
         it += 2;
     };
+    // A launch ends when its FIRST wave is through its steps: that wave raises the flag (launch + 1: the control
+    // block is zeroed per call and launches count up), every other wave leaves at its next trip.  The tracks
+    // of a roaming batch are all released (rel = 0) and a track's Philox block index follows from its own k,
+    // so nothing ties the waves' iteration counts together -- and a wave that is slower (a track on its way
+    // out of its basin pays a global atomic per visit outside the block's window: +257 clocks per pair,
+    // profiles/r03_roam_waves.txt) no longer holds the other 900 back for the 12 % it is behind.
+    const uint32_t stop_stamp = static_cast<uint32_t>(a.launch) + 1u;
+    uint32_t stop_seen = 0u;
+    bool stopped = false;
     for (; it + 8 <= a.steps; ) {
         if (!__any(static_cast<uint32_t>(it - rel) < span || (it < rel && span != 0u))) break;
+        if (a.roam_stop) {
+            // (the flag as it was one trip ago: the load is never waited for on its own)
+            if (static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(stop_seen))) == stop_stamp) { stopped = true; break; }
+            stop_seen = __hip_atomic_load(&ctl->roam_stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) one_pair();
     }
-    for (; it < a.steps; ) {                                 // a.steps is even (host)
+    for (; it < a.steps && !stopped; ) {                     // a.steps is even (host)
         if (!__any(static_cast<uint32_t>(it - rel) < span || (it < rel && span != 0u))) break;
         one_pair();
     }
+    if (a.roam_stop && !stopped && it >= a.steps && (threadIdx.x & 63) == 0) atomicMax(&ctl->roam_stop, stop_stamp);
     if (fast) { row = win_r0 + wr; col = win_c0 + wc; }
     {
         uint32_t nf = n_fine;
@@ -2858,6 +2904,21 @@ __global__ __launch_bounds__(kBlock) void k_step_roam(const StepArgs a, const Th
             atomicMax(&ctl->dbg_slowmax, (static_cast<unsigned long long>(n_slow) << 32) | n_pairs);
         }
     }
+#ifdef SSRS_DEBUG_WAVE_DUMP
+    // (diagnostic build only, tools/dev/r03_wave_dump.sh: one record per wave of ONE launch)
+    if (a.debug_roam && a.launch == SSRS_DEBUG_WAVE_DUMP && a.dbg_buf) {
+        const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_begin;
+        const int lanes = __popcll(__ballot(live0));
+        uint32_t wst = win_stray;
+        for (int off = 32; off > 0; off >>= 1) wst += __shfl_down(wst, off);
+        if ((threadIdx.x & 63) == 0) {
+            unsigned long long *r = a.dbg_buf + 8ull * (blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
+            r[0] = dt; r[1] = static_cast<unsigned long long>(lanes); r[2] = n_pairs; r[3] = n_slow; r[4] = wst;
+            r[5] = static_cast<unsigned long long>(win_r0); r[6] = static_cast<unsigned long long>(win_c0);
+            r[7] = static_cast<uint32_t>(__popcll(__ballot(fast)));
+        }
+    }
+#endif
     __syncthreads();
     for (int q = threadIdx.x; q < kWinRows * kWinCols; q += kBlock) {
         const uint32_t n = s_win[q];
@@ -4108,6 +4169,16 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
     a.thr = ws.thr;
     a.wander = ws.wander;
     a.debug_roam = std::getenv("SSRS_TRACKS_DEBUG_ROAM") != nullptr ? 1 : 0;
+    a.roam_stop = std::getenv("SSRS_TRACKS_NO_ROAM_STOP") == nullptr ? 1 : 0;
+    a.dbg_buf = nullptr;
+#ifdef SSRS_DEBUG_WAVE_DUMP
+    {
+        static unsigned long long *dump_buf = nullptr;          // (diagnostic build: never freed)
+        if (!dump_buf && a.debug_roam && hipMalloc(&dump_buf, 8ull * 8 * 4096 * (kBlock / 64)) != hipSuccess) dump_buf = nullptr;
+        if (dump_buf) (void)hipMemsetAsync(dump_buf, 0, 8ull * 8 * 4096 * (kBlock / 64), st);
+        a.dbg_buf = dump_buf;
+    }
+#endif
     a.cheap_exact = std::getenv("SSRS_TRACKS_NO_CHEAP_EXACT") == nullptr ? 1 : 0;
     a.vcap = ws.cap;
     const bool lean = p->memory_parameter == 1 && traj == nullptr;
@@ -4461,6 +4532,19 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                             ++roam_launches;
                             if (rev) hipLaunchKernelGGL(k_step_roam<true>, dim3(blocks), dim3(kBlock), 0, st, a, thr_prior);
                             else hipLaunchKernelGGL(k_step_roam<false>, dim3(blocks), dim3(kBlock), 0, st, a, thr_prior);
+#ifdef SSRS_DEBUG_WAVE_DUMP
+                            if (a.debug_roam && launch == SSRS_DEBUG_WAVE_DUMP && a.dbg_buf) {
+                                std::vector<unsigned long long> rec(8ull * blocks * (kBlock / 64));
+                                (void)hipStreamSynchronize(st);
+                                (void)hipMemcpy(rec.data(), a.dbg_buf, rec.size() * 8, hipMemcpyDeviceToHost);
+                                // block, wave, live lanes, clocks, pairs, slow pairs, strays, window origin, fast lanes
+                                for (uint32_t w = 0; w < blocks * (kBlock / 64); ++w) {
+                                    const unsigned long long *r = &rec[8ull * w];
+                                    fprintf(stderr, "W %u %u %llu %llu %llu %llu %llu %lld %lld %llu\n", w / (kBlock / 64), w % (kBlock / 64), r[1], r[0], r[2], r[3], r[4],
+                                            static_cast<long long>(r[5]), static_cast<long long>(r[6]), r[7]);
+                                }
+                            }
+#endif
                             if (a.debug_roam) {
                                 // diagnostics only: one synchronous read of the control block per launch
                                 TrackCtl c;
