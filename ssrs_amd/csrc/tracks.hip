@@ -2826,7 +2826,22 @@ __global__ __launch_bounds__(kBlock) void k_step_roam(const StepArgs a, const Th
         const int cell_a = win_cell0 + __mul24(wra, a.cols) + wca, cell_b = win_cell0 + __mul24(wrb, a.cols) + wcb;
         {
             const uint32_t cb = static_cast<uint32_t>(cell_b) < last_cell ? static_cast<uint32_t>(cell_b) : last_cell;
-            const uint32_t sidx = fast ? ((cb << 3) | ncb) : 0u;
+            uint32_t sidx = fast ? ((cb << 3) | ncb) : 0u;
+            // (timing probes, results unchanged: eight dependent / eight independent instructions in front of the
+            // gather -- +14 and +50 clocks per pair: what stands between an entry's arrival and the next gather
+            // costs its issue slots, ~4.4 clocks each, whatever its depth; profiles/r03_notes.md section 2)
+#ifdef SSRS_PROBE_CHAIN8
+            asm volatile("v_add_u32 %0, %0, 0\n v_add_u32 %0, %0, 0\n v_add_u32 %0, %0, 0\n v_add_u32 %0, %0, 0\n"
+                         "v_add_u32 %0, %0, 0\n v_add_u32 %0, %0, 0\n v_add_u32 %0, %0, 0\n v_add_u32 %0, %0, 0" : "+v"(sidx));
+#endif
+#ifdef SSRS_PROBE_IND8
+            {   // eight INDEPENDENT instructions at the same place
+                uint32_t j0 = it, j1 = it + 1, j2 = it + 2, j3 = it + 3;
+                asm volatile("v_add_u32 %0, %0, 1\n v_add_u32 %1, %1, 1\n v_add_u32 %2, %2, 1\n v_add_u32 %3, %3, 1\n"
+                             "v_add_u32 %0, %0, 1\n v_add_u32 %1, %1, 1\n v_add_u32 %2, %2, 1\n v_add_u32 %3, %3, 1" : "+v"(j0), "+v"(j1), "+v"(j2), "+v"(j3));
+                asm volatile("" : : "v"(j0), "v"(j1), "v"(j2), "v"(j3));
+            }
+#endif
             E = *reinterpret_cast<const uint4 *>(pair + (sidx << 4));
         }
         // ufi - T in {-1, 0}: within rounding of a boundary; T1 > T2 (d1 < d2): a flag entry
@@ -2837,27 +2852,33 @@ __global__ __launch_bounds__(kBlock) void k_step_roam(const StepArgs a, const Th
         // falls outside the window, adds 0 to cell 0); a visit outside the window is a global atomic and a stray
         const bool in_a = go & (static_cast<uint32_t>(wra) < static_cast<uint32_t>(kWinRows)) & (static_cast<uint32_t>(wca) < static_cast<uint32_t>(kWinCols));
         const bool in_b = go & (static_cast<uint32_t>(wrb) < static_cast<uint32_t>(kWinRows)) & (static_cast<uint32_t>(wcb) < static_cast<uint32_t>(kWinCols));
+        // the two rare continuations (a visit outside the window; a lane on the single-move sequence) behind ONE
+        // scalar test whose mask is formed early: a v_cmp -> s_cbranch_vccnz that is not taken costs a lone wave
+        // ~30 clocks (tools/microbench/latency.hip), an s_cmp on a mask that has been in SGPRs for a while next to none
+        const bool out = go & !(in_a & in_b);
+        const bool slow = (st_a | st_b) & !go;
+        const unsigned long long rare = __ballot(out | slow);
         atomicAdd(&s_win[in_a ? (wra << 8) + wca : 0], in_a ? 1u : 0u);        // ds_add_u32, nothing returned
         atomicAdd(&s_win[in_b ? (wrb << 8) + wcb : 0], in_b ? 1u : 0u);
-        const bool out = go & !(in_a & in_b);
-        if (__builtin_expect(__any(out), 0)) {
-            if (go && !in_a) { atomicAdd(&a.hist[cell_a], 1u); ++win_stray; }
-            if (go && !in_b) { atomicAdd(&a.hist[cell_b], 1u); ++win_stray; }
-        }
         k += go ? 2 : 0;
         wr = go ? wrb : wr;
         wc = go ? wcb : wc;
         rc = go ? ncb : rc0;
-        const bool slow = (st_a | st_b) & !go;
         ++n_pairs;
-        if (__builtin_expect(__any(slow), 0)) {
-            ++n_slow;
-            if (slow) {
-                if (fast) { row = win_r0 + wr; col = win_c0 + wc; }           // the state the lane stands on, as a cell again
+        if (__builtin_expect(rare != 0ull, 0)) {
+            if (__any(out)) {
+                if (go && !in_a) { atomicAdd(&a.hist[cell_a], 1u); ++win_stray; }
+                if (go && !in_b) { atomicAdd(&a.hist[cell_b], 1u); ++win_stray; }
+            }
+            if (__any(slow)) {
+                ++n_slow;
+                if (slow) {
+                    if (fast) { row = win_r0 + wr; col = win_c0 + wc; }       // the state the lane stands on, as a cell again
 #pragma unroll 1
-                for (int h = 0; h < 2; ++h)
-                    if (static_cast<uint32_t>(it + h - rel) < span) slow_step(h ? w4.z : w4.x, h ? w4.w : w4.y);
-                enter(true);
+                    for (int h = 0; h < 2; ++h)
+                        if (static_cast<uint32_t>(it + h - rel) < span) slow_step(h ? w4.z : w4.x, h ? w4.w : w4.y);
+                    enter(true);
+                }
             }
         }
         it += 2;
@@ -2872,12 +2893,11 @@ __global__ __launch_bounds__(kBlock) void k_step_roam(const StepArgs a, const Th
     uint32_t stop_seen = 0u;
     bool stopped = false;
     for (; it + 8 <= a.steps; ) {
-        if (!__any(static_cast<uint32_t>(it - rel) < span || (it < rel && span != 0u))) break;
-        if (a.roam_stop) {
-            // (the flag as it was one trip ago: the load is never waited for on its own)
-            if (static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(stop_seen))) == stop_stamp) { stopped = true; break; }
-            stop_seen = __hip_atomic_load(&ctl->roam_stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        // (one scalar test per trip; the flag as it was one trip ago: its load is never waited for on its own)
+        const unsigned long long going = __ballot(static_cast<uint32_t>(it - rel) < span || (it < rel && span != 0u));
+        const bool stop_now = a.roam_stop && static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(stop_seen))) == stop_stamp;
+        if ((going == 0ull) | stop_now) { stopped = stop_now; break; }
+        if (a.roam_stop) stop_seen = __hip_atomic_load(&ctl->roam_stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int u = 0; u < 4; ++u) one_pair();
     }

@@ -43,6 +43,18 @@ __global__ void chain(uint64_t *out, const uint32_t *mem, int iters, float seed)
         if (KIND == 10) { // s_and_saveexec / s_or exec pair around one VALU
             REP16(asm volatile("v_cmp_lt_f32 vcc, 0, %0\n s_and_saveexec_b64 s[20:21], vcc\n v_add_f32 %0, %0, %1\n s_or_b64 exec, exec, s[20:21]" : "+v"(f) : "v"(seed) : "vcc", "s20", "s21");)
         }
+        if (KIND >= 12 && KIND <= 17) {  // four independent chains of one instruction: issue rate of one wave per opcode
+            uint32_t g = u + 1u, h = u + 2u, k = u + 3u;
+            uint64_t w1 = w + 1, w2 = w + 2, w3 = w + 3;
+            if (KIND == 12) { REP16(asm volatile("v_xor_b32 %0, %0, %4\n v_xor_b32 %1, %1, %4\n v_xor_b32 %2, %2, %4\n v_xor_b32 %3, %3, %4" : "+v"(u), "+v"(g), "+v"(h), "+v"(k) : "v"(idx));) }
+            if (KIND == 13) { REP16(asm volatile("v_bitop3_b32 %0, %0, %4, s20 bitop3:0x96\n v_bitop3_b32 %1, %1, %4, s20 bitop3:0x96\n v_bitop3_b32 %2, %2, %4, s20 bitop3:0x96\n v_bitop3_b32 %3, %3, %4, s20 bitop3:0x96" : "+v"(u), "+v"(g), "+v"(h), "+v"(k) : "v"(idx) : "s20");) }
+            if (KIND == 14) { REP16(asm volatile("v_mad_u64_u32 %0, vcc, %4, %5, 0\n v_mad_u64_u32 %1, vcc, %4, %6, 0\n v_mad_u64_u32 %2, vcc, %4, %7, 0\n v_mad_u64_u32 %3, vcc, %4, %8, 0" : "+v"(w), "+v"(w1), "+v"(w2), "+v"(w3) : "v"(idx | 1u), "v"(u), "v"(g), "v"(h), "v"(k) : "vcc"); u ^= static_cast<uint32_t>(w >> 32); g ^= static_cast<uint32_t>(w1 >> 32); h ^= static_cast<uint32_t>(w2 >> 32); k ^= static_cast<uint32_t>(w3 >> 32);) }
+            if (KIND == 15) { REP16(asm volatile("v_add3_u32 %0, %0, %4, -1\n v_add3_u32 %1, %1, %4, -1\n v_add3_u32 %2, %2, %4, -1\n v_add3_u32 %3, %3, %4, -1" : "+v"(u), "+v"(g), "+v"(h), "+v"(k) : "v"(idx));) }
+            if (KIND == 16) { REP16(asm volatile("v_lshrrev_b64 %0, 1, %0\n v_lshrrev_b64 %1, 1, %1\n v_lshrrev_b64 %2, 1, %2\n v_lshrrev_b64 %3, 1, %3" : "+v"(w), "+v"(w1), "+v"(w2), "+v"(w3));) }
+            if (KIND == 17) { REP16(asm volatile("v_bfe_u32 %0, %0, %4, 2\n v_cndmask_b32 %1, %1, %4, vcc\n v_sub_u32_sdwa %2, %2, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0\n v_lshl_or_b32 %3, %3, 7, %4" : "+v"(u), "+v"(g), "+v"(h), "+v"(k) : "v"(idx) : "vcc");) }
+            u += g + h + k;
+            w += w1 + w2 + w3;
+        }
         if (KIND == 11) { // global store + dependent-free VALU (does a store stall issue?)
             REP16(asm volatile("global_store_dword %1, %0, off\n v_add_f32 %0, %0, %2" : "+v"(f) : "v"(out + 4096 + threadIdx.x), "v"(seed) : "memory");)
         }
@@ -93,6 +105,12 @@ int main()
         run<9>("s_branch (taken) + v_add", 1, d_out, d_mem, blocks, threads);
         run<10>("v_cmp + s_and_saveexec + v_add + s_or exec", 1, d_out, d_mem, blocks, threads);
         run<11>("global_store_dword + v_add", 1, d_out, d_mem, blocks, threads);
+        run<12>("4 independent v_xor_b32 chains", 4, d_out, d_mem, blocks, threads);
+        run<13>("4 independent v_bitop3_b32 (one SGPR operand)", 4, d_out, d_mem, blocks, threads);
+        run<14>("4 independent v_mad_u64_u32 (+ 4 v_xor)", 4, d_out, d_mem, blocks, threads);
+        run<15>("4 independent v_add3_u32", 4, d_out, d_mem, blocks, threads);
+        run<16>("4 independent v_lshrrev_b64", 4, d_out, d_mem, blocks, threads);
+        run<17>("v_bfe_u32, v_cndmask, v_sub_u32_sdwa, v_lshl_or_b32 (independent)", 4, d_out, d_mem, blocks, threads);
     }
     return 0;
 }
