@@ -2884,9 +2884,9 @@ __global__ __launch_bounds__(kBlock) void k_step_roam(const StepArgs a, const Th
         it += 2;
     };
     // A launch ends when its FIRST wave is through its steps: that wave raises the flag (launch + 1: the control
-    // block is zeroed per call and launches count up), every other wave leaves at its next trip.  The tracks
-    // of a roaming batch are all released (rel = 0) and a track's Philox block index follows from its own k,
-    // so nothing ties the waves' iteration counts together -- and a wave that is slower (a track on its way
+    // block is zeroed per call and launches count up), every other wave whose tracks are all released leaves at
+    // its next trip.  A released track's Philox block index follows from its own k, so nothing ties the waves'
+    // iteration counts together -- and a wave that is slower (a track on its way
     // out of its basin pays a global atomic per visit outside the block's window: +257 clocks per pair,
     // profiles/r03_roam_waves.txt) no longer holds the other 900 back for the 12 % it is behind.
     const uint32_t stop_stamp = static_cast<uint32_t>(a.launch) + 1u;
@@ -2894,9 +2894,12 @@ __global__ __launch_bounds__(kBlock) void k_step_roam(const StepArgs a, const Th
     bool stopped = false;
     for (; it + 8 <= a.steps; ) {
         // (one scalar test per trip; the flag as it was one trip ago: its load is never waited for on its own)
-        const unsigned long long going = __ballot(static_cast<uint32_t>(it - rel) < span || (it < rel && span != 0u));
-        const bool stop_now = a.roam_stop && static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(stop_seen))) == stop_stamp;
-        if ((going == 0ull) | stop_now) { stopped = stop_now; break; }
+        // (a wave with a lane that still waits for its release runs the launch out: the host counts a.steps
+        // iterations for it, and a track released one launch late would start on the odd half of a Philox block)
+        const unsigned long long stepping = __ballot(static_cast<uint32_t>(it - rel) < span), waiting = __ballot(it < rel && span != 0u);
+        const bool stop_now = a.roam_stop && waiting == 0ull &&
+                              static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(stop_seen))) == stop_stamp;
+        if (((stepping | waiting) == 0ull) | stop_now) { stopped = stop_now; break; }
         if (a.roam_stop) stop_seen = __hip_atomic_load(&ctl->roam_stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int u = 0; u < 4; ++u) one_pair();

@@ -931,6 +931,48 @@ def test_block_windows_for_batches_that_roam_basins(gpu):
     assert torch.equal(grown.hist, got.hist) and torch.equal(grown.lengths, got.lengths)
 
 
+def test_roam_launches_while_tracks_still_wait_for_their_release(gpu):
+    """Soak case 355781144 (tests/dev/soak_tracks.py): a 10 x 213 raster, 9 000 tracks, launches of 16 steps,
+    `scattered=True` -- the pair-table kernel runs from the second launch on, while most tracks still wait for
+    their release by the coherent schedule.  A wave that left such a launch early (the stop flag of k_step_roam)
+    released its tracks one launch late, on the odd half of a Philox block: lengths off by one or two.  Waves
+    with a waiting lane now run the launch out."""
+    import os
+    from ssrs_amd import movmodel
+    from oracle import c_oracle
+    rng = np.random.default_rng(355781144)
+    rows, cols = int(rng.integers(5, 400)), int(rng.integers(5, 500))
+    assert rng.random() >= 0.15
+    n = int(rng.choice([1, 7, 64, 65, 300, 2000, 9000, 20000]))
+    dirn = float(rng.choice([0., 45., 90., 135., 180., 225., 270., 315., rng.uniform(0, 360)]))
+    kind = rng.choice(['rough', 'smooth', 'flat', 'speckle', 'nan', 'wells', 'scales'])
+    assert (rows, cols, n, dirn, str(kind)) == (10, 213, 9000, 315., 'scales')
+    upd = np.abs(rng.normal(0.8, 0.6, (rows, cols)))
+    ramp = 1000. * (1 - np.arange(rows)[:, None] / max(rows - 1., 1.))
+    pot = (ramp + rng.normal(0, rng.choice([0.01, 1.0, 30.0]), (rows, cols))).astype(np.float32)
+    upd = upd * 10. ** rng.uniform(-9, 39, upd.shape)
+    upd[rng.random((rows, cols)) < 0.01] = np.inf
+    band = 10. ** rng.integers(-44, 8, rows // 8 + 1).astype(np.float64)
+    pot = (pot.astype(np.float64) * np.repeat(band, 8)[:rows, None]).astype(np.float32)
+    starts = np.stack([rng.integers(0, rows, n), rng.integers(0, cols, n)], 1)
+    s = int(rng.integers(0, 2**31))
+    ref = c_oracle.simulate_tracks(dirn, starts, (rows, cols), 1, 1., upd, pot, seed=s, want_traj=False)
+    for switch in (None, 'SSRS_TRACKS_NO_ROAM_STOP'):
+        if switch:
+            os.environ[switch] = '1'
+        try:
+            res = movmodel.simulate_tracks(dirn, starts, (rows, cols), 1, 1., upd, pot, seed=s, steps_per_launch=16,
+                                           use_table=True, thr=True, scattered=True)
+        finally:
+            if switch:
+                del os.environ[switch]
+        assert res.stats['roam_launches'] > 0, switch
+        lens, ends, hist = _no_traj_result(res)
+        assert np.array_equal(lens, ref['lengths']), switch
+        assert np.array_equal(ends, ref['ends']), switch
+        assert np.array_equal(hist, ref['hist']), switch
+
+
 def test_block_windows_when_nearly_every_track_is_trapped(gpu):
     """8192 tracks (the lists have no spare slots), a wide trough that catches most of them: the
     padded deal of the wander sort does not fit and falls back to the dense one (blocks may then mix
