@@ -173,6 +173,24 @@ constexpr uint32_t pack_ring_deltas(bool rows)
     return v;
 }
 constexpr uint32_t kRingDr = pack_ring_deltas(true), kRingDc = pack_ring_deltas(false);
+// k_step_roam: the ring position a move leads to, by which of the three intervals the uniform fell into (sel = 0, 1, 2
+// in ascending k) and the last move's ring position: 3 bits at 4 x rc; the displacements as signed 2-bit fields at
+// 4 x ring position (one shift amount serves both)
+constexpr uint32_t pack_ring_next(int sel)
+{
+    uint32_t v = 0;
+    for (int c = 0; c < 8; ++c) v |= static_cast<uint32_t>((c + 7 + ((ring_order(c) >> (2 * sel)) & 3u)) & 7u) << (4 * c);
+    return v;
+}
+constexpr uint32_t kRingNext0 = pack_ring_next(0), kRingNext1 = pack_ring_next(1), kRingNext2 = pack_ring_next(2);
+constexpr uint32_t pack_ring_deltas_signed(bool rows)
+{
+    uint32_t v = 0;
+    for (int c = 0; c < 8; ++c)
+        v |= (static_cast<uint32_t>(rows ? dr_of(kRingK[c]) : dc_of(kRingK[c])) & 3u) << (4 * c);
+    return v;
+}
+constexpr uint32_t kRingDrS = pack_ring_deltas_signed(true), kRingDcS = pack_ring_deltas_signed(false);
 constexpr uint64_t pack_ring_of_k()
 {
     uint64_t v = 0;
@@ -2672,7 +2690,6 @@ __global__ __launch_bounds__(kBlock) void k_step_roam(const StepArgs a, const Th
     }
     const char *pair = reinterpret_cast<const char *>(a.roam);
     const uint32_t ucols = static_cast<uint32_t>(a.cols);
-    const int win_cell0 = win_r0 * a.cols + win_c0;       // linear index of the window's origin (may be negative)
     const uint32_t last_cell = static_cast<uint32_t>(a.rows) * ucols - 1u;
     int k = s.k;
     // iterations [it_base, it_base + steps) of the batch; a lane steps while rel <= it < rel + span
@@ -2685,23 +2702,25 @@ __global__ __launch_bounds__(kBlock) void k_step_roam(const StepArgs a, const Th
     const unsigned long long track = a.track_base + static_cast<unsigned long long>(t);
     const char *tab = reinterpret_cast<const char *>(a.table);
     const uint32_t psh = static_cast<uint32_t>(a.plane_shift);
-    const uint32_t rev_e = pr.rev_e, rev_rc = pr.rev_rc;
+    const uint32_t rev_e = pr.rev_e;
     uint32_t win_stray = 0, n_fine = 0;
     const void *fine = a.fine;
 
-    // ---- the lane's place: window coordinates (wr, wc) -- any integers, the cell is win_cell0 + wr cols + wc --
+    // ---- the lane's place: window coordinates (wr, wc) -- any integers -- the cell as a linear index,
     // and the entry of its state.  `fast`: released and beyond its burn-in
-    int wr = 0, wc = 0;
+    int wr = 0, wc = 0, lcell = 0;                          // lcell: the same cell as a linear index (what the gather needs)
     bool fast = false;
     uint4 E = make_uint4(kThrPoison, kThrPoison, kThrPoison, kThrPoison);
     auto enter = [&](bool released) __attribute__((always_inline)) {
         wr = row - win_r0;
         wc = col - win_c0;
+        lcell = row * a.cols + col;
         fast = live0 && released && span != 0u && k > a.burnin;
-        const uint32_t sidx = fast ? (((static_cast<uint32_t>(row) * ucols + static_cast<uint32_t>(col)) << 3) | rc) : 0u;
+        const uint32_t sidx = fast ? ((static_cast<uint32_t>(lcell) << 3) | rc) : 0u;
         E = *reinterpret_cast<const uint4 *>(pair + (sidx << 4));
     };
     enter(rel == 0);
+    const uint32_t rev_rc4 = 4u * pr.rev_rc;
 
     // ---- one move by the rules of k_step_thr's special branch, written plainly (rare: ~1 % of the pairs)
     auto slow_step = [&](const uint32_t w0, const uint32_t w1) __attribute__((always_inline)) {
@@ -2796,54 +2815,46 @@ __global__ __launch_bounds__(kBlock) void k_step_roam(const StepArgs a, const Th
         // (copies into locals before any select: see k_step_thr on selects of captured variables)
         const uint32_t q0 = E.x, qa = E.y, qb = E.z, qc = E.w;
         const uint32_t rc0 = rc;
-        // ---- first move: the decode of k_step_thr's roaming variants (a reversal row is an ordinary row of
-        // the move along the heading with the prior's thresholds)
+        const uint32_t rc04 = 4u * rc0;                                         // (before the entry is there)
+        // What stands between an entry's arrival and the next gather costs ~4.4 clocks per instruction, whatever
+        // its depth (profiles/r03_notes.md section 2), so the way to the next state is as short as it gets: which
+        // of the three intervals the uniform fell into (two compares), the ring position that leads to from a
+        // packed constant (selected by the compares, 3 bits at 3 x last move), the displacement as signed 2-bit
+        // fields, the cell as a linear index.  Window coordinates, the visits and the special tests follow the gather.
+        // ---- first move (a reversal row is an ordinary row of the move along the heading with the prior's thresholds)
         const bool rva = REV && q0 == kThrReversal;
-        const uint32_t eua = rva ? rev_e : q0, rcda = rva ? rev_rc : rc0;
-        const int32_t a1 = static_cast<int32_t>(ufa) - static_cast<int32_t>(eua & 0xFFFFu);
-        const int32_t a2 = static_cast<int32_t>(ufa) - static_cast<int32_t>(eua >> 16);
-        const uint32_t orda = static_cast<uint32_t>(kRingOrder >> __umul24(6u, rcda)) & 63u;
-        const uint32_t nega = (static_cast<uint32_t>(a1) >> 31) + (static_cast<uint32_t>(a2) >> 31);      // 2 - sel
-        const uint32_t nca = (rcda + 7u + ((orda >> (4u - 2u * nega)) & 3u)) & 7u;
-        const uint32_t q1 = nega == 2u ? qa : (nega == 1u ? qb : qc);          // the entry of the cell it leads to
-        const int wra = wr + static_cast<int>((kRingDr >> (2u * nca)) & 3u) - 1;
-        const int wca = wc + static_cast<int>((kRingDc >> (2u * nca)) & 3u) - 1;
+        const uint32_t eua = rva ? rev_e : q0;
+        const uint32_t t4a = rva ? rev_rc4 : rc04;
+        const bool ga1 = ufa >= (eua & 0xFFFFu), ga2 = ufa >= (eua >> 16);       // sel = ga1 + ga2 (T1 <= T2 unless flagged)
+        const uint32_t nxa = ga2 ? kRingNext2 : (ga1 ? kRingNext1 : kRingNext0);   // (constants: a select of captured variables would be a select of their addresses)
+        const uint32_t nca = (nxa >> t4a) & 7u, nca4 = 4u * nca;
+        const uint32_t q1 = ga2 ? qc : (ga1 ? qb : qa);                          // the entry of the cell it leads to
+        const int dra = __builtin_amdgcn_sbfe(static_cast<int>(kRingDrS), nca4, 2u), dca = __builtin_amdgcn_sbfe(static_cast<int>(kRingDcS), nca4, 2u);
+        const int cell_a = lcell + __mul24(dra, a.cols) + dca;
         // ---- second move
         const bool rvb = REV && q1 == kThrReversal;
-        const uint32_t eub = rvb ? rev_e : q1, rcdb = rvb ? rev_rc : nca;
-        const int32_t b1 = static_cast<int32_t>(ufb) - static_cast<int32_t>(eub & 0xFFFFu);
-        const int32_t b2 = static_cast<int32_t>(ufb) - static_cast<int32_t>(eub >> 16);
-        const uint32_t ordb = static_cast<uint32_t>(kRingOrder >> __umul24(6u, rcdb)) & 63u;
-        const uint32_t negb = (static_cast<uint32_t>(b1) >> 31) + (static_cast<uint32_t>(b2) >> 31);
-        const uint32_t ncb = (rcdb + 7u + ((ordb >> (4u - 2u * negb)) & 3u)) & 7u;
-        const int wrb = wra + static_cast<int>((kRingDr >> (2u * ncb)) & 3u) - 1;
-        const int wcb = wca + static_cast<int>((kRingDc >> (2u * ncb)) & 3u) - 1;
+        const uint32_t eub = rvb ? rev_e : q1;
+        const uint32_t t4b = rvb ? rev_rc4 : nca4;
+        const bool gb1 = ufb >= (eub & 0xFFFFu), gb2 = ufb >= (eub >> 16);
+        const uint32_t nxb = gb2 ? kRingNext2 : (gb1 ? kRingNext1 : kRingNext0);
+        const uint32_t ncb = (nxb >> t4b) & 7u, ncb4 = 4u * ncb;
+        const int drb = __builtin_amdgcn_sbfe(static_cast<int>(kRingDrS), ncb4, 2u), dcb = __builtin_amdgcn_sbfe(static_cast<int>(kRingDcS), ncb4, 2u);
+        const int cell_b = cell_a + __mul24(drb, a.cols) + dcb;
         // the next entry, before anything else is known.  A lane that takes the pair from the table ends on
         // a cell of the raster; one that does not (it stands on a boundary cell, a flag entry, a near-tie)
         // may point up to two rows outside it -- the index is clamped into the table (a negative one wraps to
-        // a large unsigned) and the lane looks its state up again below, so what it loads here is never used
-        // (24-bit multiplies: |window row| < 2^16 and cols < 2^15; the 32-bit one runs at a quarter of the rate)
-        const int cell_a = win_cell0 + __mul24(wra, a.cols) + wca, cell_b = win_cell0 + __mul24(wrb, a.cols) + wcb;
+        // a large unsigned) and the lane looks its state up again below, so what it loads here is never used;
+        // nor is what a lane loads that does not step (it holds a cell of the raster all the same)
         {
             const uint32_t cb = static_cast<uint32_t>(cell_b) < last_cell ? static_cast<uint32_t>(cell_b) : last_cell;
-            uint32_t sidx = fast ? ((cb << 3) | ncb) : 0u;
-            // (timing probes, results unchanged: eight dependent / eight independent instructions in front of the
-            // gather -- +14 and +50 clocks per pair: what stands between an entry's arrival and the next gather
-            // costs its issue slots, ~4.4 clocks each, whatever its depth; profiles/r03_notes.md section 2)
-#ifdef SSRS_PROBE_CHAIN8
-            asm volatile("v_add_u32 %0, %0, 0\n v_add_u32 %0, %0, 0\n v_add_u32 %0, %0, 0\n v_add_u32 %0, %0, 0\n"
-                         "v_add_u32 %0, %0, 0\n v_add_u32 %0, %0, 0\n v_add_u32 %0, %0, 0\n v_add_u32 %0, %0, 0" : "+v"(sidx));
-#endif
-#ifdef SSRS_PROBE_IND8
-            {   // eight INDEPENDENT instructions at the same place
-                uint32_t j0 = it, j1 = it + 1, j2 = it + 2, j3 = it + 3;
-                asm volatile("v_add_u32 %0, %0, 1\n v_add_u32 %1, %1, 1\n v_add_u32 %2, %2, 1\n v_add_u32 %3, %3, 1\n"
-                             "v_add_u32 %0, %0, 1\n v_add_u32 %1, %1, 1\n v_add_u32 %2, %2, 1\n v_add_u32 %3, %3, 1" : "+v"(j0), "+v"(j1), "+v"(j2), "+v"(j3));
-                asm volatile("" : : "v"(j0), "v"(j1), "v"(j2), "v"(j3));
-            }
-#endif
-            E = *reinterpret_cast<const uint4 *>(pair + (sidx << 4));
+            E = *reinterpret_cast<const uint4 *>(pair + ((cb << 7) | (ncb4 << 2)));
         }
+        // ---- behind the gather: window coordinates of the two visits, the tests
+        const int wra = wr + dra, wca = wc + dca, wrb = wra + drb, wcb = wca + dcb;
+        const int32_t a1 = static_cast<int32_t>(ufa) - static_cast<int32_t>(eua & 0xFFFFu);
+        const int32_t a2 = static_cast<int32_t>(ufa) - static_cast<int32_t>(eua >> 16);
+        const int32_t b1 = static_cast<int32_t>(ufb) - static_cast<int32_t>(eub & 0xFFFFu);
+        const int32_t b2 = static_cast<int32_t>(ufb) - static_cast<int32_t>(eub >> 16);
         // ufi - T in {-1, 0}: within rounding of a boundary; T1 > T2 (d1 < d2): a flag entry
         const bool special = (static_cast<uint32_t>(a1 + 1) < 2u) | (static_cast<uint32_t>(a2 + 1) < 2u) | (a1 < a2) |
                              (static_cast<uint32_t>(b1 + 1) < 2u) | (static_cast<uint32_t>(b2 + 1) < 2u) | (b1 < b2);
@@ -2863,6 +2874,7 @@ __global__ __launch_bounds__(kBlock) void k_step_roam(const StepArgs a, const Th
         k += go ? 2 : 0;
         wr = go ? wrb : wr;
         wc = go ? wcb : wc;
+        lcell = go ? cell_b : lcell;
         rc = go ? ncb : rc0;
         ++n_pairs;
         if (__builtin_expect(rare != 0ull, 0)) {
