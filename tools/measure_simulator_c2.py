@@ -1,7 +1,7 @@
 """ssrs_amd.Simulator end to end at BASELINE configs[1] (5000 x 6000 @10 m): constructor (K1 +
 file), simulate_tracks, presence map.  Three runs: the ramp stand-in potential (seeded through
 the <id>_potential.npy cache of the file contract) with and without tracks.pkl, and the solved
-potential (10 000 tracks, no pickle: a third of them run to max_moves)."""
+potential (10 000 and 100 000 tracks, no pickle: a third of them run to max_moves)."""
 import os, sys, time, tempfile, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -36,3 +36,4 @@ def run(tag, tracks, save, seed_ramp):
 run('ramp potential, 100k tracks, save_tracks=False', 100_000, False, True)
 run('ramp potential, 100k tracks, save_tracks=True ', 100_000, True, True)
 run('solved potential, 10k tracks, save_tracks=False', 10_000, False, False)
+run('solved potential, 100k tracks, save_tracks=False', 100_000, False, False)      # the bench's workload, through the API
