@@ -31,6 +31,7 @@ struct AmgHierarchy {
     int strong_rounds = 4;         // matching rounds restricted to strong couplings (of 8)
     int kdepth = 0;                // coarse levels 1..kdepth use the K-cycle (0 = V-cycle)
     int sweeps = 1;                // pairs of Jacobi sweeps before and after the coarse correction
+    double om[2] = {0.7, 0.7};     // step sizes of a pair of sweeps (SSRS_AMG_OMEGAS=a,b for experiments)
     // level 0 applied matrix-free (amg.hip: L0Stencil)
     const double *l0_rinv = nullptr;
     const uint8_t *l0_fixed = nullptr;

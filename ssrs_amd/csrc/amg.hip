@@ -334,10 +334,10 @@ __global__ __launch_bounds__(kBlock) void k_unpack_coarse(const unsigned long lo
 // ---- cycle kernels --------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_jacobi_first(const double *__restrict__ dinv,
                                                         const double *__restrict__ b, int n,
-                                                        double *__restrict__ x)
+                                                        double *__restrict__ x, double w)
 {
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
-        x[i] = kOmega * dinv[i] * b[i];
+        x[i] = w * dinv[i] * b[i];
 }
 
 // Four lanes per row for the large CSR levels: a thread-per-row walk reads val/col
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(kBlock) void k_jacobi4(const int *__restrict__ rowp
                                                    const double *__restrict__ dinv,
                                                    const double *__restrict__ b,
                                                    const double *__restrict__ x, int n,
-                                                   double *__restrict__ xn)
+                                                   double *__restrict__ xn, double w)
 {
     const int sub = threadIdx.x % kRowLanes;
     const long long groups = static_cast<long long>(gridDim.x) * (kBlock / kRowLanes);
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(kBlock) void k_jacobi4(const int *__restrict__ rowp
         rows_dot4(rowptr, col, val, x, row, n, sub, ax);
 #pragma unroll
         for (int u = 0; u < kRowsPerGroup; ++u)
-            if (sub == 0 && row[u] < n) xn[row[u]] = x[row[u]] + kOmega * dinv[row[u]] * (b[row[u]] - ax[u]);
+            if (sub == 0 && row[u] < n) xn[row[u]] = x[row[u]] + w * dinv[row[u]] * (b[row[u]] - ax[u]);
     }
 }
 
@@ -460,12 +460,12 @@ __global__ __launch_bounds__(kBlock) void k_jacobi(const int *__restrict__ rowpt
                                                   const double *__restrict__ dinv,
                                                   const double *__restrict__ b,
                                                   const double *__restrict__ x, int n,
-                                                  double *__restrict__ xn)
+                                                  double *__restrict__ xn, double w)
 {
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         double ax = 0.0;
         for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) ax += val[p] * x[col[p]];
-        xn[i] = x[i] + kOmega * dinv[i] * (b[i] - ax);
+        xn[i] = x[i] + w * dinv[i] * (b[i] - ax);
     }
 }
 
@@ -572,14 +572,14 @@ __device__ __forceinline__ double l0_apply_wave(const L0Stencil &a, const double
 __global__ __launch_bounds__(kBlock) void k_l0_jacobi(L0Stencil a, const double *__restrict__ dinv,
                                                      const double *__restrict__ b,
                                                      const double *__restrict__ x,
-                                                     double *__restrict__ xn)
+                                                     double *__restrict__ xn, double w)
 {
     const int c = (static_cast<int>(blockIdx.x) * (kBlock / 64) + static_cast<int>(threadIdx.x >> 6)) * kL0Cols +
                   static_cast<int>(threadIdx.x & 63) - 1;
     bool centre;
     size_t i;
     const double ax = l0_apply_wave(a, x, static_cast<int>(blockIdx.y), c, centre, i);
-    if (centre) xn[i] = x[i] + kOmega * dinv[i] * (b[i] - ax);
+    if (centre) xn[i] = x[i] + w * dinv[i] * (b[i] - ax);
 }
 
 __global__ __launch_bounds__(kBlock) void k_l0_residual(L0Stencil a, const double *__restrict__ b,
@@ -1032,22 +1032,22 @@ static dim3 l0_grid(const AmgHierarchy &h)
     return dim3(static_cast<unsigned>((h.l0_cols + per_block - 1) / per_block), static_cast<unsigned>(h.l0_rows));
 }
 
-static void launch_jacobi(AmgHierarchy &h, size_t lev, const double *x, double *xn, hipStream_t st)
+static void launch_jacobi(AmgHierarchy &h, size_t lev, const double *x, double *xn, hipStream_t st, double w = kOmega)
 {
     AmgLevel &L = h.levels[lev];
     if (lev == 0 && h.l0_rinv && !getenv("SSRS_AMG_L0_CSR")) {
         const L0Stencil a{h.l0_rinv, h.l0_fixed, h.l0_rows, h.l0_cols};
-        hipLaunchKernelGGL(k_l0_jacobi, l0_grid(h), dim3(kBlock), 0, st, a, L.dinv, L.b, x, xn);
+        hipLaunchKernelGGL(k_l0_jacobi, l0_grid(h), dim3(kBlock), 0, st, a, L.dinv, L.b, x, xn, w);
     } else {
         const dim3 g4(grid_for((static_cast<size_t>(L.n) + kRowsPerGroup - 1) / kRowsPerGroup * kRowLanes)), g1(grid_for(L.n));
         if (L.n >= kVectorRows && L.val32)
-            hipLaunchKernelGGL(k_jacobi4<float>, g4, dim3(kBlock), 0, st, L.rowptr, L.col, L.val32, L.dinv, L.b, x, L.n, xn);
+            hipLaunchKernelGGL(k_jacobi4<float>, g4, dim3(kBlock), 0, st, L.rowptr, L.col, L.val32, L.dinv, L.b, x, L.n, xn, w);
         else if (L.n >= kVectorRows)
-            hipLaunchKernelGGL(k_jacobi4<double>, g4, dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.dinv, L.b, x, L.n, xn);
+            hipLaunchKernelGGL(k_jacobi4<double>, g4, dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.dinv, L.b, x, L.n, xn, w);
         else if (L.val32)
-            hipLaunchKernelGGL(k_jacobi<float>, g1, dim3(kBlock), 0, st, L.rowptr, L.col, L.val32, L.dinv, L.b, x, L.n, xn);
+            hipLaunchKernelGGL(k_jacobi<float>, g1, dim3(kBlock), 0, st, L.rowptr, L.col, L.val32, L.dinv, L.b, x, L.n, xn, w);
         else
-            hipLaunchKernelGGL(k_jacobi<double>, g1, dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.dinv, L.b, x, L.n, xn);
+            hipLaunchKernelGGL(k_jacobi<double>, g1, dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.dinv, L.b, x, L.n, xn, w);
     }
 }
 
@@ -1086,20 +1086,22 @@ static void cycle(AmgHierarchy &h, size_t lev, hipStream_t st)
             hipLaunchKernelGGL(k_dense_apply, dim3(gd), dim3(kBlock), 0, st, h.dense_inv, L.r, n, L.xt);
             hipLaunchKernelGGL(k_axpy1, dim3(g), dim3(kBlock), 0, st, L.xt, n, L.x);
         } else {                                   // stalled coarsening: relax
-            hipLaunchKernelGGL(k_jacobi_first, dim3(g), dim3(kBlock), 0, st, L.dinv, L.b, n, L.x);
+            hipLaunchKernelGGL(k_jacobi_first, dim3(g), dim3(kBlock), 0, st, L.dinv, L.b, n, L.x, kOmega);
             for (int s = 0; s < 20; ++s) {
-                hipLaunchKernelGGL(k_jacobi, dim3(g), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.dinv, L.b, L.x, n, L.xt);
-                hipLaunchKernelGGL(k_jacobi, dim3(g), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.dinv, L.b, L.xt, n, L.x);
+                hipLaunchKernelGGL(k_jacobi, dim3(g), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.dinv, L.b, L.x, n, L.xt, kOmega);
+                hipLaunchKernelGGL(k_jacobi, dim3(g), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.dinv, L.b, L.xt, n, L.x, kOmega);
             }
         }
         return;
     }
     // pre-smoothing: 2*sweeps Jacobi sweeps from x = 0
-    hipLaunchKernelGGL(k_jacobi_first, dim3(g), dim3(kBlock), 0, st, L.dinv, L.b, n, L.xt);
-    launch_jacobi(h, lev, L.xt, L.x, st);
+    // (step sizes of a pair of sweeps: h.om[0], h.om[1] before the coarse correction, the same in reverse after it --
+    // the smoother stays self-adjoint in the D inner product whatever the two are)
+    hipLaunchKernelGGL(k_jacobi_first, dim3(g), dim3(kBlock), 0, st, L.dinv, L.b, n, L.xt, h.om[0]);
+    launch_jacobi(h, lev, L.xt, L.x, st, h.om[1]);
     for (int s = 1; s < h.sweeps; ++s) {
-        launch_jacobi(h, lev, L.x, L.xt, st);
-        launch_jacobi(h, lev, L.xt, L.x, st);
+        launch_jacobi(h, lev, L.x, L.xt, st, h.om[0]);
+        launch_jacobi(h, lev, L.xt, L.x, st, h.om[1]);
     }
     launch_residual(h, lev, st);
     AmgLevel &C = h.levels[lev + 1];
@@ -1108,8 +1110,8 @@ static void cycle(AmgHierarchy &h, size_t lev, hipStream_t st)
     hipLaunchKernelGGL(k_prolong_add, dim3(g), dim3(kBlock), 0, st, L.agg, C.x, n, L.x);
     // post-smoothing
     for (int s = 0; s < h.sweeps; ++s) {
-        launch_jacobi(h, lev, L.x, L.xt, st);
-        launch_jacobi(h, lev, L.xt, L.x, st);
+        launch_jacobi(h, lev, L.x, L.xt, st, h.om[1]);
+        launch_jacobi(h, lev, L.xt, L.x, st, h.om[0]);
     }
 }
 

@@ -18,6 +18,7 @@
 // Dirichlet cells come from the host (MovModel.get_boundary_nodes restated in
 // ssrs_amd/potential.py) as a mask + value raster.
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 
 #include "amg.h"
@@ -533,6 +534,10 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
         ~AmgGuard() { amg_release(h); }
     } amg_guard{amg};
     amg.sweeps = 1 + ((flags >> 4) & 7);
+    if (const char *e = std::getenv("SSRS_AMG_OMEGAS")) {
+        double a0 = 0.7, a1 = 0.7;
+        if (std::sscanf(e, "%lf,%lf", &a0, &a1) == 2 && a0 > 0.0 && a1 > 0.0) { amg.om[0] = a0; amg.om[1] = a1; }
+    }
     amg.kdepth = (flags & SSRS_SOLVE_K_CYCLE) ? (((flags >> 12) & 15) ? ((flags >> 12) & 15) : 3) : 0;
     amg.symmetric = (flags & SSRS_SOLVE_ONE_SIDED) == 0;
     amg.strong_rounds = ((flags >> 8) & 15) ? ((flags >> 8) & 15) : 4;
