@@ -686,6 +686,7 @@ static_assert(sizeof(TrackCtl) <= 128 * sizeof(uint32_t), "final read-back slot 
 // block histogram windows of wandering batches (k_step_thr<6>, k_wander_windows)
 constexpr int kWinRows = 144, kWinCols = 256;      // 144 KB of LDS: one block per CU
 constexpr int kWanderWindows = 16;
+constexpr uint32_t kWanderMix = 256;                 // low bits of a sort key: a per-sort hash of the track (k_wander_keys)
 constexpr uint32_t kDealBlocks = 232;              // blocks the contiguous deal spreads the live tracks over (+ one per
                                                    // window in use and the padding: under the 256 CUs)
 constexpr int kBinRows = kWinRows / 4, kBinCols = kWinCols / 4;
@@ -3657,21 +3658,28 @@ __global__ __launch_bounds__(1024) void k_wander_windows(const int32_t *__restri
 
 __global__ __launch_bounds__(kBlock) void k_wander_keys(const int32_t *__restrict__ list_in, const TrackState *__restrict__ state,
                                                        const TrackCtl *__restrict__ ctl, int in_slot, uint32_t cap,
-                                                       const WanderWindows *__restrict__ win, uint32_t *__restrict__ keys)
+                                                       const WanderWindows *__restrict__ win, uint32_t *__restrict__ keys, uint32_t salt)
 {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= cap * kXcd) return;
     const uint32_t x = i / cap, il = i - x * cap;
     uint32_t key = kWanderWindows + 1;                               // dead slot
+    uint32_t mix = 0;
     if (il < ctl->count[in_slot][x]) {
         const int32_t t = list_in[i];
         if (t >= 0) {
             const int32_t pos = state[t].pos;
             key = static_cast<uint32_t>(wander_window_of(win, win->n, pos & 0xFFFF, (pos >> 16) & 0xFFFF));
             if (key >= static_cast<uint32_t>(win->n)) key = kWanderWindows;   // outside every window
+            // salt != 0 (a sort of a settled batch): the tracks of a window in an order of its own every time, so
+            // that nobody keeps the same wave-mates -- a wave that carries a track on its way out of the basin
+            // is slower, and tracks that stay with it fall behind for good
+            uint32_t h = (static_cast<uint32_t>(t) + salt) * 0x9E3779B1u;
+            h ^= h >> 15; h *= 0x85EBCA6Bu; h ^= h >> 13;
+            mix = salt ? (h & (kWanderMix - 1u)) : 0u;
         }
     }
-    keys[i] = key;
+    keys[i] = key * kWanderMix + mix;
 }
 
 __global__ __launch_bounds__(1024) void k_deal_sorted(const uint32_t *__restrict__ sorted_keys, const int32_t *__restrict__ sorted,
@@ -3688,7 +3696,7 @@ __global__ __launch_bounds__(1024) void k_deal_sorted(const uint32_t *__restrict
         uint32_t a = 0, b = slots;
         while (a < b) {
             const uint32_t m = (a + b) / 2;
-            if (sorted_keys[m] < threadIdx.x) a = m + 1; else b = m;
+            if (sorted_keys[m] / kWanderMix < threadIdx.x) a = m + 1; else b = m;
         }
         lo[threadIdx.x] = a;
     }
@@ -4300,7 +4308,10 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
     const bool lds_rows = lds_rows_env != nullptr;
     a.lr_wait = (lds_rows && std::atoi(lds_rows_env) == 2) ? 1 : 0;
     bool roam_ready = false;
-    int roam_launches = 0, stable_roam = 0;
+    int roam_launches = 0, stable_roam = 0, since_shuffle = 0;
+    bool sort_is_periodic = false;
+    int roam_shuffle = 16;                   // batches between two shuffles of a settled roaming batch (SSRS_TRACKS_ROAM_SHUFFLE, 0: never)
+    if (const char *e = std::getenv("SSRS_TRACKS_ROAM_SHUFFLE")) roam_shuffle = std::atoi(e);
     int roam_steps = 128 * S;                // A/B: SSRS_TRACKS_ROAM_STEPS (4096: 0.0073, 16384: 0.0060, 65536: 0.0053 ns per step at C2)
     if (const char *e = std::getenv("SSRS_TRACKS_ROAM_STEPS")) {
         const int v = std::atoi(e);
@@ -4384,10 +4395,10 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
             hipLaunchKernelGGL(k_wander_windows, dim3(1), dim3(1024), 0, st, ws.list[launch & 1], ws.state, ws.ctl, launch & 3, ws.cap,
                                p->rows, p->cols, ws.wander);
             hipLaunchKernelGGL(k_wander_keys, dim3((slots + kBlock - 1) / kBlock), dim3(kBlock), 0, st, ws.list[launch & 1], ws.state,
-                               ws.ctl, launch & 3, ws.cap, ws.wander, k0);
+                               ws.ctl, launch & 3, ws.cap, ws.wander, k0, sort_is_periodic ? static_cast<uint32_t>(launch) : 0u);
             size_t temp_bytes = ws.sort_temp_bytes;
             if (hipcub::DeviceRadixSort::SortPairs(ws.sort_temp, temp_bytes, k0, k1, ws.list[launch & 1], sorted,
-                                                   static_cast<int>(slots), 0, 5, st) != hipSuccess) {
+                                                   static_cast<int>(slots), 0, 13, st) != hipSuccess) {
                 rc = set_error(SSRS_ERR_HIP, "wander sort failed");
                 break;
             }
@@ -4398,7 +4409,8 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
             want_wander_sort = false;
             want_rebalance = false;
             wander_cooldown = 3;
-            stable_roam = 0;
+            stable_roam = sort_is_periodic ? 2 : 0;      // (a shuffle of a settled batch: the launches stay long)
+            sort_is_periodic = false;
             marks_adjacent = false;
             // the padded deal makes the lists LONGER (each window's run is rounded up to whole blocks of
             // every list): raise the bound now, and let no batch queued before this point lower it
@@ -4774,7 +4786,11 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                             dsteps ? static_cast<double>(dstray) / static_cast<double>(dsteps) : 0.0, total);
                 if (wander_cooldown > 0) --wander_cooldown;
                 else if (dsteps > 0 && dstray * 64 > dsteps && wander_sorts < 12) want_wander_sort = true;
-                else ++stable_roam;                     // settled in its windows: the launches may grow
+                else if (roam_shuffle > 0 && ++since_shuffle >= roam_shuffle && stable_roam >= 2 && roam_ready) {
+                    want_wander_sort = true;            // settled: every roam_shuffle batches the windows' tracks are dealt afresh
+                    sort_is_periodic = true;
+                    since_shuffle = 0;
+                } else ++stable_roam;                   // settled in its windows: the launches may grow
             }
             // batches that never binned (small, unsorted, very wide rasters) give no stray
             // signal: tracks still alive after four raster crossings are wandering
