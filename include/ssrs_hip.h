@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SSRS_VERSION 104 /* 0.1.4 */
+#define SSRS_VERSION 105 /* 0.1.5 */
 
 #define SSRS_OK 0
 #define SSRS_ERR_INVALID (-1) /* bad argument (message says which) */
@@ -125,6 +125,23 @@ int ssrs_wind_from_lattice(const double *lattice_speed, const double *lattice_di
                            int nx, int ny, double x0, double y0, double dx, double dy,
                            double cell_size, double *wspeed, double *wdirn, int rows,
                            int cols, int batch, void *stream);
+
+/* The same for SCATTERED samples -- the reference's general case, ssrs/simulator.py:765-776:
+ * scipy.interpolate.griddata(points, values, mesh, method='linear'), i.e. a Delaunay triangulation of the sample
+ * points and barycentric interpolation inside each triangle, applied to the east / north components (:778-792).
+ * The triangulation is the caller's: `points` (npts, 2) f64 in the raster's length unit relative to the centre of
+ * cell (0, 0) (x along columns, y along rows), `triangles` (ntri, 3) int32 vertex indices and `transform` (ntri, 3, 2)
+ * f64 exactly as scipy.spatial.Delaunay(points) holds them (.simplices, .transform: the 2 x 2 inverse of the edge
+ * matrix and the offset r) -- griddata builds that very object.  speed / dirn (batch, npts) f64 -> wspeed / wdirn
+ * (batch, rows, cols) f64, direction in [0, 360); cells outside the convex hull are NaN (griddata's fill value).  A
+ * cell on an edge shared by two triangles takes the one with the lower index (the interpolant is continuous there;
+ * scipy's walk picks either), so results agree with griddata to rounding, not bit for bit.
+ * workspace: ssrs_wind_triangles_workspace_bytes(npts, rows, cols, batch) bytes of device scratch. */
+size_t ssrs_wind_triangles_workspace_bytes(int npts, int rows, int cols, int batch);
+int ssrs_wind_from_triangles(const double *points, const int32_t *triangles, const double *transform,
+                             const double *speed, const double *dirn, int npts, int ntri,
+                             double cell_size, double *wspeed, double *wdirn, int rows, int cols,
+                             int batch, void *workspace, size_t workspace_bytes, void *stream);
 
 /* compute_thermals (ssrs/layers.py:188-214), split in its two stages.
  * ssrs_thermal_seeds: per-cell seeding inside the 10 % border with probability

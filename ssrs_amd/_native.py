@@ -26,7 +26,7 @@ EXPORTS = (
     'ssrs_version', 'ssrs_build_flags', 'ssrs_last_error', 'ssrs_device_info', 'ssrs_slope_aspect',
     'ssrs_orographic_updraft', 'ssrs_threshold_updraft', 'ssrs_updraft_from_dem',
     'ssrs_lattice_workspace_bytes', 'ssrs_updraft_from_dem_lattice',
-    'ssrs_wind_from_lattice', 'ssrs_thermal_seeds', 'ssrs_blur_workspace_bytes',
+    'ssrs_wind_from_lattice', 'ssrs_wind_triangles_workspace_bytes', 'ssrs_wind_from_triangles', 'ssrs_thermal_seeds', 'ssrs_blur_workspace_bytes',
     'ssrs_gaussian_blur', 'ssrs_track_params_init', 'ssrs_transition_table_build',
     'ssrs_transition_ring_bytes', 'ssrs_transition_ring_build',
     'ssrs_transition_thr_bytes', 'ssrs_transition_thr_build',
@@ -91,6 +91,8 @@ def lib():
         L.ssrs_tracks_workspace_bytes.restype = C.c_size_t
         L.ssrs_tracks_workspace_bytes.argtypes = [C.c_int64]
         L.ssrs_lattice_workspace_bytes.restype = C.c_size_t
+        L.ssrs_wind_triangles_workspace_bytes.restype = C.c_size_t
+        L.ssrs_wind_triangles_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
         L.ssrs_lattice_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
         L.ssrs_tracks_workspace_bytes_ex.restype = C.c_size_t
         L.ssrs_tracks_workspace_bytes_ex.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int]

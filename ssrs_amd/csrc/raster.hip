@@ -594,6 +594,73 @@ __global__ __launch_bounds__(kBlock) void k_lattice_components(const double *__r
     }
 }
 
+// Scattered wind samples (the reference's general case, simulator.py:765-776: scipy griddata, method 'linear' =
+// Delaunay triangulation + barycentric interpolation).  The triangulation is the host's (scipy.spatial.Delaunay, the
+// very object griddata builds); here: (1) every triangle claims the cells of its bounding box whose centre it
+// contains -- by scipy's own test, all barycentric coordinates within [-eps, 1 + eps], eps = 100 DBL_EPSILON -- and the
+// LOWEST triangle index wins a cell on a shared edge (deterministic; the interpolant is continuous there);
+// (2) per cell: c_j = sum_k T[j][k] (x_k - r_k), c_2 = 1 - c_0 - c_1 from the triangulation's affine transform,
+// east / north = sum_j c_j value[vertex_j] in scipy's order, then the u/v recipe of simulator.py:778-792.  Cells
+// outside the hull are NaN, as griddata's fill value.
+__global__ __launch_bounds__(kBlock) void k_tri_owner(const double *__restrict__ pts, const int32_t *__restrict__ tri,
+                                                     const double *__restrict__ transform, int ntri, double cell,
+                                                     int rows, int cols, int32_t *__restrict__ owner)
+{
+    const int t = blockIdx.x;
+    if (t >= ntri) return;
+    const int32_t v0 = tri[3 * t], v1 = tri[3 * t + 1], v2 = tri[3 * t + 2];
+    const double x0 = pts[2 * v0], y0 = pts[2 * v0 + 1], x1 = pts[2 * v1], y1 = pts[2 * v1 + 1], x2 = pts[2 * v2], y2 = pts[2 * v2 + 1];
+    const double xmin = fmin(x0, fmin(x1, x2)), xmax = fmax(x0, fmax(x1, x2));
+    const double ymin = fmin(y0, fmin(y1, y2)), ymax = fmax(y0, fmax(y1, y2));
+    // cells whose centre (c cell, r cell) may lie in the box, one cell of margin for the tolerance
+    long long c_lo = static_cast<long long>(floor(xmin / cell)) - 1, c_hi = static_cast<long long>(ceil(xmax / cell)) + 1;
+    long long r_lo = static_cast<long long>(floor(ymin / cell)) - 1, r_hi = static_cast<long long>(ceil(ymax / cell)) + 1;
+    c_lo = c_lo < 0 ? 0 : c_lo;  r_lo = r_lo < 0 ? 0 : r_lo;
+    c_hi = c_hi > cols - 1 ? cols - 1 : c_hi;  r_hi = r_hi > rows - 1 ? rows - 1 : r_hi;
+    if (c_lo > c_hi || r_lo > r_hi) return;
+    const double *T = transform + 6 * static_cast<size_t>(t);        // [T00 T01; T10 T11; r0 r1]
+    const double t00 = T[0], t01 = T[1], t10 = T[2], t11 = T[3], rx = T[4], ry = T[5];
+    if (!(t00 == t00)) return;                                         // degenerate simplex (scipy: NaN transform)
+    const double eps = 100.0 * 2.220446049250313e-16;
+    const long long w = c_hi - c_lo + 1, n = w * (r_hi - r_lo + 1);
+    for (long long q = static_cast<long long>(blockIdx.y) * kBlock + threadIdx.x; q < n; q += static_cast<long long>(gridDim.y) * kBlock) {
+        const long long r = r_lo + q / w, c = c_lo + q % w;
+        const double dx = static_cast<double>(c) * cell - rx, dy = static_cast<double>(r) * cell - ry;
+        const double b0 = t00 * dx + t01 * dy, b1 = t10 * dx + t11 * dy, b2 = 1.0 - b0 - b1;
+        const bool inside = b0 >= -eps && b0 <= 1.0 + eps && b1 >= -eps && b1 <= 1.0 + eps && b2 >= -eps && b2 <= 1.0 + eps;
+        if (inside) atomicMin(&owner[static_cast<size_t>(r) * cols + static_cast<size_t>(c)], t);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_wind_triangles(const int32_t *__restrict__ owner, const int32_t *__restrict__ tri,
+                                                          const double *__restrict__ transform,
+                                                          const double *__restrict__ east, const double *__restrict__ north,
+                                                          int npts, double cell, double *__restrict__ wspeed,
+                                                          double *__restrict__ wdirn, int rows, int cols, int batch)
+{
+    const size_t ncell = static_cast<size_t>(rows) * cols, total = ncell * batch;
+    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < total; i += static_cast<size_t>(gridDim.x) * kBlock) {
+        const int b = static_cast<int>(i / ncell);
+        const size_t c0 = i - static_cast<size_t>(b) * ncell;
+        const int r = static_cast<int>(c0 / cols), c = static_cast<int>(c0 % cols);
+        const int32_t t = owner[c0];
+        double spd = __longlong_as_double(0x7FF8000000000000ll), ang = spd;
+        if (t != 0x7f7f7f7f) {
+            const double *T = transform + 6 * static_cast<size_t>(t);
+            const double dx = static_cast<double>(c) * cell - T[4], dy = static_cast<double>(r) * cell - T[5];
+            const double b0 = T[0] * dx + T[1] * dy, b1 = T[2] * dx + T[3] * dy, b2 = 1.0 - b0 - b1;
+            const double *e = east + static_cast<size_t>(b) * npts, *nn = north + static_cast<size_t>(b) * npts;
+            const int32_t v0 = tri[3 * t], v1 = tri[3 * t + 1], v2 = tri[3 * t + 2];
+            const double ee = b0 * e[v0] + b1 * e[v1] + b2 * e[v2];     // (left to right, as scipy sums them)
+            const double en = b0 * nn[v0] + b1 * nn[v1] + b2 * nn[v2];
+            spd = sqrt(ee * ee + en * en);
+            ang = fmod(atan2(ee, en) + 2.0 * kPi, 2.0 * kPi) * 180.0 / kPi;
+        }
+        wspeed[i] = spd;
+        wdirn[i] = ang;
+    }
+}
+
 // Snapshot / seasonal K1: DEM tile in LDS -> Horn sums once per cell, then for every
 // snapshot b the wind at the cell (bilinear in the lattice's east / north components,
 // as k_wind_lattice) and the updraft in the trig-free form of k_updraft_from_dem: with
@@ -744,6 +811,38 @@ extern "C" int ssrs_wind_from_lattice(const double *lattice_speed, const double 
     hipLaunchKernelGGL(k_wind_lattice, dim3(stream_grid(total)), dim3(kBlock), 0,
                        as_stream(stream), lattice_speed, lattice_dirn, nx, ny, x0, y0, dx, dy,
                        cell_size, wspeed, wdirn, rows, cols, batch);
+    SSRS_HIP_CHECK(hipGetLastError());
+    return SSRS_OK;
+}
+
+extern "C" size_t ssrs_wind_triangles_workspace_bytes(int npts, int rows, int cols, int batch)
+{
+    if (npts <= 0 || rows <= 0 || cols <= 0 || batch <= 0) return 0;
+    return static_cast<size_t>(rows) * cols * sizeof(int32_t) + 2 * static_cast<size_t>(npts) * batch * sizeof(double) + 512;
+}
+
+extern "C" int ssrs_wind_from_triangles(const double *points, const int32_t *triangles, const double *transform,
+                                        const double *speed, const double *dirn, int npts, int ntri, double cell_size,
+                                        double *wspeed, double *wdirn, int rows, int cols, int batch,
+                                        void *workspace, size_t workspace_bytes, void *stream)
+{
+    SSRS_REQUIRE(points && triangles && transform && speed && dirn && wspeed && wdirn,
+                 "ssrs_wind_from_triangles: NULL pointer");
+    SSRS_REQUIRE(npts >= 3 && ntri >= 1 && rows > 0 && cols > 0 && batch > 0, "ssrs_wind_from_triangles: bad sizes");
+    SSRS_REQUIRE(cell_size > 0.0, "ssrs_wind_from_triangles: cell_size must be > 0");
+    SSRS_REQUIRE(workspace && workspace_bytes >= ssrs_wind_triangles_workspace_bytes(npts, rows, cols, batch),
+                 "ssrs_wind_from_triangles: workspace too small");
+    hipStream_t st = as_stream(stream);
+    const size_t ncell = static_cast<size_t>(rows) * cols, nval = static_cast<size_t>(npts) * batch;
+    int32_t *owner = static_cast<int32_t *>(workspace);
+    double *east = reinterpret_cast<double *>(static_cast<char *>(workspace) + ((ncell * sizeof(int32_t) + 255) / 256) * 256);
+    double *north = east + nval;
+    SSRS_HIP_CHECK(hipMemsetAsync(owner, 0x7f, ncell * sizeof(int32_t), st));      // 0x7f7f7f7f: above any index
+    hipLaunchKernelGGL(k_lattice_components, dim3(stream_grid(nval)), dim3(kBlock), 0, st, speed, dirn, nval, east, north);
+    hipLaunchKernelGGL(k_tri_owner, dim3(static_cast<unsigned>(ntri), 64), dim3(kBlock), 0, st, points, triangles, transform, ntri,
+                       cell_size, rows, cols, owner);
+    hipLaunchKernelGGL(k_wind_triangles, dim3(stream_grid(ncell * batch)), dim3(kBlock), 0, st, owner, triangles, transform, east,
+                       north, npts, cell_size, wspeed, wdirn, rows, cols, batch);
     SSRS_HIP_CHECK(hipGetLastError());
     return SSRS_OK;
 }

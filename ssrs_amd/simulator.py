@@ -226,7 +226,7 @@ class Simulator(Config):
         # per batch, no per-cell wind rasters, no slope / aspect rasters)
         mine = set(self._cases_written_here())
         wind = [it for it in self._wind if it['case_id'] in mine]
-        lattice = len(wind) > 0 and all('x_km' in it for it in wind) and \
+        lattice = len(wind) > 0 and all('x_km' in it and np.ndim(it['wspeed']) == 2 for it in wind) and \
             not ('Slope' in self._terrain or 'Aspect' in self._terrain) and \
             all(np.array_equal(it['x_km'], wind[0]['x_km']) and
                 np.array_equal(it['y_km'], wind[0]['y_km']) for it in wind)
@@ -262,7 +262,12 @@ class Simulator(Config):
         """Per-cell wind speed / direction (f64 device tensors) of one case."""
         ws, wd = item['wspeed'], item['wdirn']
         if 'x_km' in item:
-            from .wind import interpolate_wind_lattice
+            from .wind import interpolate_wind_lattice, interpolate_wind_scattered
+            # samples on a regular lattice (x_km[nx], y_km[ny], arrays (ny, nx)) or at scattered points
+            # (x_km[npts], y_km[npts], arrays (npts,)): the reference's griddata, simulator.py:765-776
+            if np.ndim(ws) == 1 and np.size(item['x_km']) == np.size(ws) == np.size(item['y_km']):
+                return interpolate_wind_scattered(item['x_km'], item['y_km'], ws, wd,
+                                                  self.gridsize, self.resolution)
             return interpolate_wind_lattice(item['x_km'], item['y_km'], ws, wd,
                                             self.gridsize, self.resolution)
         ws = to_dev(ws, torch.float64)
