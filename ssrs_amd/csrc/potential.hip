@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "amg.h"
 #include "common.h"
@@ -446,6 +447,27 @@ __global__ __launch_bounds__(kBlock) void k_setup(StencilArgs a, const double *_
     if (threadIdx.x == 0) s->part[4][blockIdx.x] = d;
 }
 
+// diagnostics (SSRS_PROGRESS): where a recomputed residual sits -- sums of r^2 over live cells (cond != 0), dead cells
+// and the east-edge column, the largest |r| and its cell
+__global__ __launch_bounds__(kBlock) void k_resid_breakdown(StencilArgs a, const double *__restrict__ r, double *__restrict__ out)
+{
+    const size_t n = static_cast<size_t>(a.rows) * a.cols;
+    double live = 0.0, dead = 0.0, east = 0.0, big = 0.0;
+    unsigned long long where = 0;
+    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * kBlock) {
+        const double v = r[i];
+        const bool is_dead = a.rinv ? a.rinv[i] == 0.0 : a.cond[i] == 0.0;
+        if (static_cast<int>(i % a.cols) == a.cols - 1) east += v * v;
+        else if (is_dead) dead += v * v;
+        else live += v * v;
+        if (fabs(v) > big) { big = fabs(v); where = i; }
+    }
+    atomicAdd(&out[0], live); atomicAdd(&out[1], dead); atomicAdd(&out[2], east);
+    // (max by the bit pattern of a non-negative double; the cell of the last writer that held the maximum)
+    const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(big));
+    if (atomicMax(reinterpret_cast<unsigned long long *>(&out[3]), bits) < bits) reinterpret_cast<unsigned long long *>(out)[4] = where;
+}
+
 __global__ __launch_bounds__(kBlock) void k_init_x(const uint8_t *__restrict__ fixed,
                                                   const double *__restrict__ fixed_val,
                                                   const double *__restrict__ guess, double fill,
@@ -594,6 +616,10 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
         hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, st, sc, FIN_INIT, nb);
         double cg_best = 1e300;
         int stalled = 0;
+        // where PCG hands over: the exact operator's residual of the symmetric problem's solution (the quirk's
+        // defect) is ~1e-6 of the right-hand side, so BiCGStab starts from there whatever PCG reached below it
+        double pcg_tol = rel_tol;
+        if (const char *e = std::getenv("SSRS_SOLVE_PCG_TOL")) { const double v = std::atof(e); if (v > rel_tol) pcg_tol = v; }
         while (cg_iterations < max_iterations) {
             for (int j = 0; j < 5; ++j, ++cg_iterations) {
                 // flexible CG(1): the K-cycle preconditioner is slightly non-linear,
@@ -615,11 +641,39 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
             SSRS_HIP_CHECK(hipStreamSynchronize(st));
             if (!(host[0] == host[0])) break;
             const double now = host[1] > 0.0 ? std::sqrt(host[0] / host[1]) : 0.0;
-            if (progress && cg_iterations % 250 == 0)
+            if (progress && (cg_iterations % 250 == 0 || std::atoi(std::getenv("SSRS_PROGRESS")) >= 2))   // (=2: every check)
                 fprintf(stderr, "[ssrs_potential_solve] PCG it %d |r|/|b| %.3e\n", cg_iterations, now);
-            if (now <= rel_tol) break;
+            if (now <= pcg_tol) break;
             if (now < 0.9 * cg_best) { cg_best = now; stalled = 0; }
             else if (++stalled >= 100) break;          // 500 iterations without a 10 % gain
+        }
+        if (progress) {
+            // what PCG's carried residual is worth: recomputed with the symmetric and with the exact operator
+            for (int q = 0; q < 2; ++q) {
+                StencilArgs aq = a;
+                aq.quirk = q;
+                hipLaunchKernelGGL(k_setup, dim3(nb), dim3(kBlock), 0, st, aq, x, r, rhat, p, v, sc);
+                hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, st, sc, FIN_INIT, nb);
+                SSRS_HIP_CHECK(hipMemcpyAsync(host, &sc->rnorm2, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+                SSRS_HIP_CHECK(hipStreamSynchronize(st));
+                fprintf(stderr, "[ssrs_potential_solve] after PCG (%d iterations): recomputed |r|/|b| %.3e with the %s operator\n", cg_iterations,
+                        host[1] > 0.0 ? std::sqrt(host[0] / host[1]) : 0.0, q ? "exact (east-edge quirk)" : "symmetric");
+                {
+                    double *dbg = nullptr;
+                    if (hipMalloc(&dbg, 8 * sizeof(double)) == hipSuccess) {
+                        (void)hipMemsetAsync(dbg, 0, 8 * sizeof(double), st);
+                        hipLaunchKernelGGL(k_resid_breakdown, dim3(1024), dim3(kBlock), 0, st, aq, r, dbg);
+                        double hb[8];
+                        (void)hipMemcpyAsync(hb, dbg, sizeof(hb), hipMemcpyDeviceToHost, st);
+                        (void)hipStreamSynchronize(st);
+                        unsigned long long wcell;
+                        memcpy(&wcell, &hb[4], sizeof(wcell));
+                        fprintf(stderr, "    sum r^2: live cells %.3e, dead cells %.3e, east-edge column %.3e (|b|^2 %.3e); largest |r| %.3e at row %llu col %llu\n",
+                                hb[0], hb[1], hb[2], host[1], hb[3], wcell / a.cols, wcell % a.cols);
+                        (void)hipFree(dbg);
+                    }
+                }
+            }
         }
         // hand over to BiCGStab on the exact operator
         hipLaunchKernelGGL(k_setup, dim3(nb), dim3(kBlock), 0, st, a, x, r, rhat, p, v, sc);
@@ -656,7 +710,7 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
         SSRS_HIP_CHECK(hipStreamSynchronize(st));
         const bool finite = host[0] == host[0] && host[0] < 1e300;
         const double now = finite && host[1] > 0.0 ? std::sqrt(host[0] / host[1]) : (finite ? 0.0 : 1e300);
-        if (progress && it % 250 == 0)
+        if (progress && (it % 250 == 0 || std::atoi(std::getenv("SSRS_PROGRESS")) >= 2))
             fprintf(stderr, "[ssrs_potential_solve] BiCGStab it %d |r|/|b| %.3e\n", it, now);
         if (finite && now < best) {
             best = now;
@@ -675,6 +729,15 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
         }
     }
     if (best < 1e300) SSRS_HIP_CHECK(hipMemcpyAsync(x, xbest, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (progress) {
+        // the residual the iteration carried along against the one recomputed from x
+        hipLaunchKernelGGL(k_setup, dim3(nb), dim3(kBlock), 0, st, a, x, r, rhat, p, v, sc);
+        hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, st, sc, FIN_INIT, nb);
+        SSRS_HIP_CHECK(hipMemcpyAsync(host, &sc->rnorm2, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+        SSRS_HIP_CHECK(hipStreamSynchronize(st));
+        fprintf(stderr, "[ssrs_potential_solve] done: carried |r|/|b| %.3e, recomputed %.3e (PCG %d + BiCGStab %d iterations)\n", rel,
+                host[1] > 0.0 ? std::sqrt(host[0] / host[1]) : 0.0, cg_iterations, it);
+    }
     hipLaunchKernelGGL(k_to_f32, dim3(nb), dim3(kBlock), 0, st, x, potential, n);
     SSRS_HIP_CHECK(hipGetLastError());
     SSRS_HIP_CHECK(hipEventRecord(e1, st));
