@@ -56,6 +56,8 @@ def parse():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--tracks', type=int, default=100_000, help='tracks per GPU')
+    ap.add_argument('--hist-safe-tracks', type=int, default=200_000,
+                    help='tracks per sub-batch of a pass (a uint32 histogram is safe for this many on the solved field)')
     ap.add_argument('--resolution', type=float, default=10.0)
     ap.add_argument('--width-km', type=float, nargs=2, default=(60.0, 50.0))
     ap.add_argument('--direct', action='store_true', help='3x3 window gathers, no table')
@@ -213,6 +215,22 @@ def chain_probe(args, movmodel, layers, dem, pot, starts_h, gridsize, res, seed)
                     'shallower than S steps)'}
 
 
+class _MergedPass:
+    """The sub-batches of one pass as one result: lengths in track order, stats added up."""
+
+    def __init__(self, outs):
+        import torch
+        self.lengths = torch.cat([o.lengths for o in outs])
+        keys = set().union(*[o.stats.keys() for o in outs])
+        self.stats = {}
+        for k in keys:
+            vals = [o.stats.get(k, 0) for o in outs]
+            if all(isinstance(v, (int, float)) and not isinstance(v, bool) for v in vals):
+                self.stats[k] = sum(vals)
+            else:
+                self.stats[k] = vals[0]
+
+
 class Passes:
     """K timed passes of the hot path on one potential field (the main leg and the stand-in leg)."""
 
@@ -233,6 +251,7 @@ class Passes:
                         wander_sorts=0, roam_launches=0, roam_wave_pairs=0, roam_slow_wave_pairs=0, roam_fine_settled=0)
 
     def one_step(self, timed):
+        import torch
         args, ev, acc = self.args, self.ev, self.acc
         slot = self.step_no % len(self.hists)
         self.step_no += 1
@@ -246,14 +265,29 @@ class Passes:
         ev[1].record()
         table = None if args.direct else build_table(args, self.movmodel, upd, self.pot)
         ev[2].record()
-        out = self.movmodel.simulate_tracks(0.0, self.starts, self.gridsize, 1, 1.0, upd, self.pot, seed=self.seed,
-                                            track_id_base=self.lo, table=table, use_table=not args.direct,
-                                            hist=hist, steps_per_launch=args.steps_per_launch,
-                                            profile=True, exact_only=args.exact_only,
-                                            schedule=not args.no_schedule, binning=not args.no_binning)
+        n = int(self.starts.shape[0])
+        safe = max(int(args.hist_safe_tracks), 1)
+        outs = []
+        hist64 = None
+        # more tracks than a uint32 histogram is safe for (trap cells of the solved field collect ~1e4 visits per
+        # track): sub-batches added up in 64 bits, as ssrs_amd.Simulator does (Config.hist_safe_tracks)
+        for b0 in range(0, n, safe):
+            if n > safe:
+                if hist64 is None:
+                    hist64 = torch.zeros(self.gridsize, dtype=torch.int64, device=hist.device)
+                hist.zero_()
+            o = self.movmodel.simulate_tracks(0.0, self.starts[b0:b0 + safe], self.gridsize, 1, 1.0, upd, self.pot, seed=self.seed,
+                                              track_id_base=self.lo + b0, table=table, use_table=not args.direct,
+                                              hist=hist, steps_per_launch=args.steps_per_launch,
+                                              profile=True, exact_only=args.exact_only,
+                                              schedule=not args.no_schedule, binning=not args.no_binning)
+            outs.append(o)
+            if hist64 is not None:
+                hist64 += hist.to(torch.int64) & 0xFFFFFFFF
+        out = outs[0] if len(outs) == 1 else _MergedPass(outs)
         # (widens to 64 bits by itself when the ranks' largest counts could wrap a 32-bit sum)
-        self.pending[slot] = self.reduce_histogram(hist, dst=0, async_op=True)
-        self.reduced[slot] = self.pending[slot].result if self.pending[slot] is not None else hist
+        self.pending[slot] = self.reduce_histogram(hist if hist64 is None else hist64, dst=0, async_op=True)
+        self.reduced[slot] = self.pending[slot].result if self.pending[slot] is not None else (hist if hist64 is None else hist64)
         ev[3].record()
         if timed:
             # simulate_tracks returned after its last launch completed, so the
