@@ -44,10 +44,12 @@ RASTER_BYTES_PER_CELL = 20      # fused K1 as benchmarked: f64 DEM in (8) + f32 
 # steps/s of the stepper once the GPU is FULL of waves: what a latency-bound batch of 100k tracks is
 # measured against (`throughput_frac`).  Front-shaped batches (k_step_thr<4>): 1 M tracks per GPU on the
 # ramp, every SIMD holding several waves (profiles/r02_scale_tracks.txt, 40.6 M tracks/s x 4 850 steps).
-# Roaming batches (k_step_roam, one block of 144 KB LDS per CU): every CU holding a FULL block of 256 tracks
-# (profiles/r03_roam_fill.txt)
+# Roaming batches (k_step_roam, one block of 144 KB LDS per CU): every CU holding a nearly FULL block of 256 tracks --
+# 140 000 tracks per pass with the round's final kernel (profiles/r03_roam_fill.txt: 2.84e11; more tracks need a
+# second round of blocks).  A pass takes the time of its longest track chain whatever the number of tracks, so this
+# is what the same 1.35 s could carry, not something a 100k-track pass can reach.
 THROUGHPUT_BOUND_STEPS_PER_S = 2.0e11
-ROAM_THROUGHPUT_BOUND_STEPS_PER_S = 2.1e11
+ROAM_THROUGHPUT_BOUND_STEPS_PER_S = 2.84e11
 
 
 def parse():

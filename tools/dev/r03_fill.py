@@ -11,7 +11,7 @@ dem = torch.from_numpy(synthetic_dem(SHAPE, RES)).cuda()
 _, upd = layers.updraft_from_dem(dem, RES, 10., 270., threshold=0.75)
 pot = solve_potential(upd, 0.)
 table = movmodel.build_transition_table(upd, pot, thr=True, move_dirn=0.)
-for n in (50_000, 100_000, 150_000, 200_000, 300_000):
+for n in (50_000, 100_000, 125_000, 140_000, 150_000, 200_000, 300_000):
     np.random.seed(30)
     r, c = movmodel.get_starting_indices(n, (5, 55, 1, 2), 'random', (60., 50.), RES)
     starts = np.stack([r, c], 1).astype(np.int32)
