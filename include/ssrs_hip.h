@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SSRS_VERSION 105 /* 0.1.5 */
+#define SSRS_VERSION 106 /* 0.1.6 */
 
 #define SSRS_OK 0
 #define SSRS_ERR_INVALID (-1) /* bad argument (message says which) */
@@ -225,6 +225,9 @@ typedef struct SsrsTrackStats {
     int64_t roam_wave_pairs;      /* pairs of moves run by the waves of those launches ... */
     int64_t roam_slow_wave_pairs; /* ... and how many of them sent some lane through the single-move sequence
                                      (near-ties, flag entries, moves out of the window, burn-in) */
+    int32_t roam_shuffles;        /* times a SETTLED roaming batch had the tracks of its windows dealt afresh
+                                     (every SSRS_TRACKS_ROAM_SHUFFLE batches, default 16; part of wander_sorts) */
+    int32_t reserved1;
 } SsrsTrackStats;
 
 /* Fills rows/cols/burnin/max_moves/memory/nu and zeroes the rest; `prior` must

@@ -34,6 +34,7 @@ def lib():
         _lib.orc_uniform.restype = C.c_double
         _lib.orc_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
         _lib.orc_simulate_tracks.restype = C.c_int64
+        _lib.orc_simulate_tracks_ids.restype = C.c_int64
         _lib.orc_num_threads.restype = C.c_int
     return _lib
 
@@ -65,9 +66,10 @@ def uniform(seed, track, step):
 
 def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
                     scaling_parameter=1.0, updraft=None, potential=None, seed=0,
-                    track_id_base=0, want_traj=True, want_hist=True, nthreads=0, max_moves=None):
+                    track_id_base=0, want_traj=True, want_hist=True, nthreads=0, max_moves=None, track_ids=None):
     """Returns dict(lengths int32[n], ends int16[n,2], hist uint32[R,C] | None,
-    tracks list[int16[n_i,2]] | None, steps int)."""
+    tracks list[int16[n_i,2]] | None, steps int).  `track_ids` (uint64[n]): the global ids of an arbitrary
+    subset of a batch (default: track_id_base + 0..n-1)."""
     L = lib()
     rows, cols = grid_shape
     starts = np.ascontiguousarray(np.asarray(starts, dtype=np.int32).reshape(-1, 2))
@@ -84,18 +86,22 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
     lengths = np.zeros(n, dtype=np.int32)
     ends = np.zeros((n, 2), dtype=np.int16)
     hist = np.zeros((rows, cols), dtype=np.uint32) if want_hist else None
+    ids = None
+    if track_ids is not None:
+        ids = np.ascontiguousarray(track_ids, dtype=np.uint64)
+        assert ids.shape == (n,)
     args = [C.byref(p), _ptr(upd, C.c_double), _ptr(pot, C.c_float),
             _ptr(starts, C.c_int32), C.c_int64(n), C.c_uint64(seed),
-            C.c_uint64(track_id_base)]
+            C.c_uint64(track_id_base), _ptr(ids, C.c_uint64)]
     traj = offs = None
     if want_traj:   # pass 1: lengths; pass 2: trajectories
-        steps = L.orc_simulate_tracks(*args, None, None, _ptr(lengths, C.c_int32),
+        steps = L.orc_simulate_tracks_ids(*args, None, None, _ptr(lengths, C.c_int32),
                                       None, None, C.c_int(nthreads))
         assert steps >= 0
         offs = np.zeros(n + 1, dtype=np.int64)
         np.cumsum(lengths, out=offs[1:])
         traj = np.zeros((int(offs[-1]), 2), dtype=np.int16)
-    steps = L.orc_simulate_tracks(*args, _ptr(hist, C.c_uint32), _ptr(ends, C.c_int16),
+    steps = L.orc_simulate_tracks_ids(*args, _ptr(hist, C.c_uint32), _ptr(ends, C.c_int16),
                                   _ptr(lengths, C.c_int32), _ptr(traj, C.c_int16),
                                   _ptr(offs, C.c_int64), C.c_int(nthreads))
     if steps < 0:

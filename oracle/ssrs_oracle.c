@@ -285,11 +285,32 @@ static int64_t run_track(const orc_params *p, const double *updraft,
 /* Simulate `ntracks` tracks.  hist/end_rc/lengths/traj may each be NULL.
  * traj layout: int16 pairs at traj[2*traj_offsets[t] ...].  Returns total steps
  * (sum of lengths - ntracks) or -1 on bad arguments. */
+int64_t orc_simulate_tracks_ids(const orc_params *p, const double *updraft,
+                                const float *potential, const int32_t *start_rc,
+                                int64_t ntracks, uint64_t seed, uint64_t track_id_base,
+                                const uint64_t *track_ids,
+                                uint32_t *hist, int16_t *end_rc, int32_t *lengths,
+                                int16_t *traj, const int64_t *traj_offsets, int nthreads);
+
 int64_t orc_simulate_tracks(const orc_params *p, const double *updraft,
                             const float *potential, const int32_t *start_rc,
                             int64_t ntracks, uint64_t seed, uint64_t track_id_base,
                             uint32_t *hist, int16_t *end_rc, int32_t *lengths,
                             int16_t *traj, const int64_t *traj_offsets, int nthreads)
+{
+    return orc_simulate_tracks_ids(p, updraft, potential, start_rc, ntracks, seed, track_id_base, NULL,
+                                   hist, end_rc, lengths, traj, traj_offsets, nthreads);
+}
+
+/* The same for an arbitrary SUBSET of a batch: track t draws from the stream of global id
+ * track_ids[t] (NULL: track_id_base + t) -- the tracks of a batch are independent given their ids
+ * (simulator.py:360 maps them over a pool), so any subset can be checked on its own. */
+int64_t orc_simulate_tracks_ids(const orc_params *p, const double *updraft,
+                                const float *potential, const int32_t *start_rc,
+                                int64_t ntracks, uint64_t seed, uint64_t track_id_base,
+                                const uint64_t *track_ids,
+                                uint32_t *hist, int16_t *end_rc, int32_t *lengths,
+                                int16_t *traj, const int64_t *traj_offsets, int nthreads)
 {
     if (!p || p->rows < 5 || p->cols < 5 || p->memory < 0 || p->memory > 60) return -1;
     if (potential && !updraft) return -1;
@@ -305,7 +326,7 @@ int64_t orc_simulate_tracks(const orc_params *p, const double *updraft,
     for (int64_t t = 0; t < ntracks; ++t) {
         int16_t *tj = (traj && traj_offsets) ? traj + 2 * traj_offsets[t] : NULL;
         int64_t n = run_track(p, updraft, potential, start_rc[2 * t], start_rc[2 * t + 1],
-                              seed, track_id_base + (uint64_t)t, rmask, hist, tj,
+                              seed, track_ids ? track_ids[t] : track_id_base + (uint64_t)t, rmask, hist, tj,
                               end_rc ? end_rc + 2 * t : NULL);
         if (lengths) lengths[t] = (int32_t)n;
         total += n - 1;

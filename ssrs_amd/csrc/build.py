@@ -47,7 +47,7 @@ def build(force=False, verbose=False):
 
 
 def build_probe(defines, tag):
-    """Timing-probe variant of the library (tools/probe_chain.py): tracks.hip recompiled with
+    """Timing-probe variant of the library (tools/attic/probe_chain.py): tracks.hip recompiled with
     -D<defines>, linked with the product's other objects into libssrs_probe_<tag>.so."""
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     build()

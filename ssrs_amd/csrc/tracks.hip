@@ -3850,6 +3850,8 @@ static size_t workspace_layout(int64_t n, char *base, Workspace *ws)
 
 // pinned host words for the live-count read-back, one set per host thread
 constexpr int kFinalSlot = 384;      // words: the read-back ring (8 slots of 40) ends at 320
+constexpr int kHeaderSlot = 336;     // words 336..357: a threshold table's header, read back before the first launch
+static_assert(kHeaderSlot >= 320 && kHeaderSlot % 2 == 0 && kHeaderSlot * 4 + sizeof(ThrHeader) <= kFinalSlot * 4, "header slot");
 static uint32_t *pinned_counts()
 {
     static thread_local uint32_t *buf = nullptr;
@@ -4146,6 +4148,23 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
     const int mode = table ? MODE_TABLE : (updraft ? (potential ? MODE_FLUIDFLOW : MODE_UPDRAFT)
                                                    : MODE_PRIOR);
 
+    if (p->flags & SSRS_TRACKS_THR_TABLE) {
+        // A threshold table names its raster and prior in its leading guard band.  The header is read back
+        // and checked HERE, before any stepper kernel gathers from the table: a table built for a smaller
+        // raster would send those gathers out of bounds (k_ctl_init's device-side check of the same
+        // header is only acted on when the run is over).  88 bytes and one stream wait per call.
+        SSRS_REQUIRE(table != nullptr, "ssrs_tracks_simulate: SSRS_TRACKS_THR_TABLE needs `table`");
+        ThrHeader *hh = reinterpret_cast<ThrHeader *>(host_counts + kHeaderSlot);
+        SSRS_HIP_CHECK(hipMemcpyAsync(hh, table, sizeof(ThrHeader), hipMemcpyDeviceToHost, st));
+        SSRS_HIP_CHECK(hipStreamSynchronize(st));
+        bool bad = hh->magic != kThrMagic || hh->rows != p->rows || hh->cols != p->cols;
+        for (int k = 0; k < 9; ++k) bad |= hh->prior[k] != p->prior[k];
+        if (bad)
+            return set_error(SSRS_ERR_INVALID, "ssrs_tracks_simulate: `table` is not a threshold table built by "
+                             "ssrs_transition_thr_build for this %d x %d raster and params->prior (nothing was launched)",
+                             p->rows, p->cols);
+    }
+
     hipEvent_t ev_first = nullptr, ev_last = nullptr;
     SSRS_HIP_CHECK(hipEventCreate(&ev_first));
     SSRS_HIP_CHECK(hipEventCreate(&ev_last));
@@ -4308,7 +4327,7 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
     const bool lds_rows = lds_rows_env != nullptr;
     a.lr_wait = (lds_rows && std::atoi(lds_rows_env) == 2) ? 1 : 0;
     bool roam_ready = false;
-    int roam_launches = 0, stable_roam = 0, since_shuffle = 0;
+    int roam_launches = 0, stable_roam = 0, since_shuffle = 0, roam_shuffles = 0;
     bool sort_is_periodic = false;
     int roam_shuffle = 16;                   // batches between two shuffles of a settled roaming batch (SSRS_TRACKS_ROAM_SHUFFLE, 0: never)
     if (const char *e = std::getenv("SSRS_TRACKS_ROAM_SHUFFLE")) roam_shuffle = std::atoi(e);
@@ -4410,6 +4429,7 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
             want_rebalance = false;
             wander_cooldown = 3;
             stable_roam = sort_is_periodic ? 2 : 0;      // (a shuffle of a settled batch: the launches stay long)
+            if (sort_is_periodic) ++roam_shuffles;
             sort_is_periodic = false;
             marks_adjacent = false;
             // the padded deal makes the lists LONGER (each window's run is rounded up to whole blocks of
@@ -4842,6 +4862,7 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
         stats->block_window_launches = block_window_launches;
         stats->wander_sorts = wander_sorts;
         stats->roam_launches = roam_launches;
+        stats->roam_shuffles = roam_shuffles;
         stats->roam_wave_pairs = static_cast<int64_t>(host_ctl.roam_pairs);
         stats->roam_slow_wave_pairs = static_cast<int64_t>(host_ctl.roam_slow);
         stats->reserved0 = static_cast<int32_t>(host_ctl.pad);                   // near-ties settled by the fine table

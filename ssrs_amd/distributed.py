@@ -47,14 +47,6 @@ class HistogramOverflow(OverflowError):
     the multi-rank reduce widens instead of raising)."""
 
 
-def _max_bound(hist, group):
-    """Sum over ranks of each rank's largest count (int64 scalar tensor): an upper bound
-    of the largest count of the reduced histogram."""
-    local = _local_max(hist.view(torch.int32).reshape(-1))
-    dist.all_reduce(local, op=dist.ReduceOp.SUM, group=group)
-    return local
-
-
 def _local_max(flat):
     """Upper bound of the largest count of a uint32-in-int32 histogram as an int64 scalar
     tensor: one pass (aminmax), no host synchronisation.  A negative int32 is a count >= 2^31;
@@ -94,8 +86,7 @@ def reduce_histogram(hist, dst=0, group=None, all_ranks=False, async_op=False, g
     in place or the widened 64-bit sum is queued on the collective's stream and runs under the
     next batch's stepper launches; ``wait()`` orders the current stream after it and
     ``handle.result`` is the tensor that holds the sum (the caller must not touch `hist`
-    before ``wait()``).  Round 2's asynchronous form raised HistogramOverflow from ``wait()``
-    instead of widening, which aborted an 8-GPU run on the solved field by design."""
+    before ``wait()``).  With guard=False every rank must pass the same dtype."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return None if async_op else hist
 
@@ -104,16 +95,21 @@ def reduce_histogram(hist, dst=0, group=None, all_ranks=False, async_op=False, g
             return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, **kw)
         return dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM, group=group, **kw)
 
-    if hist.dtype == torch.int64:
-        # already widened (a rank that stepped its tracks in sub-batches): a plain 64-bit sum
-        if async_op:
-            return _GuardedWork(run(hist.reshape(-1), async_op=True), hist)
-        run(hist.reshape(-1))
-        return hist
-    flat = hist.view(torch.int32).reshape(-1)
+    # Every rank takes the SAME sequence of collectives whatever its local dtype: a rank that stepped its
+    # tracks in sub-batches arrives with int64 counts while a rank one track short of the split arrives
+    # with int32 (shard sizes differ by one).  The ranks therefore agree on the width first: an already
+    # widened rank contributes 2^32 to the bound, which sends every rank down the wide path.
+    already_wide = hist.dtype == torch.int64
+    flat = hist.reshape(-1) if already_wide else hist.view(torch.int32).reshape(-1)
+    need_wide = already_wide
+    if guard:
+        local = torch.full((1,), 1 << 32, dtype=torch.int64, device=hist.device) if already_wide \
+            else _local_max(flat)
+        dist.all_reduce(local, op=dist.ReduceOp.SUM, group=group)
+        need_wide = int(local.item()) >= (1 << 32)
     wide = None
-    if guard and int(_max_bound(hist, group).item()) >= (1 << 32):
-        wide = flat.to(torch.int64) & 0xFFFFFFFF
+    if need_wide:
+        wide = flat if already_wide else flat.to(torch.int64) & 0xFFFFFFFF
     if async_op:
         if wide is not None:
             return _GuardedWork(run(wide, async_op=True), wide.reshape(hist.shape))

@@ -84,7 +84,7 @@ def solve_potential(updraft, move_dirn, rel_tol=1e-15, max_iterations=2000,
     guess = to_dev(initial_guess, torch.float64)
     out = torch.empty((rows, cols), dtype=torch.float32, device=cond.device)
     # ssrs_potential_workspace_bytes is a safe upper bound (1.5 KB per cell: 45 GB at 5000 x 6000);
-    # the hierarchy really takes ~840 B per cell (tools/probe_solver_footprint.py), so the first
+    # the hierarchy really takes ~840 B per cell (tools/attic/probe_solver_footprint.py), so the first
     # try reserves 1.1 KB per cell and only a solve that runs out of it takes the full bound
     full = nat.lib().ssrs_potential_workspace_bytes(rows, cols)
     first = min(full, (1100 * rows * cols + (96 << 20)) // 256 * 256)

@@ -165,6 +165,13 @@ class Simulator(Config):
                 item['case_id'] = dt.strftime(self.time_format)       # simulator.py:126
             item['datetime'] = dt
             out.append(item)
+        if any('x_km' in it for it in out) and str(self.wtk_interp_type).lower() != 'linear':
+            # the reference hands wtk_interp_type to scipy's griddata ('nearest' | 'linear' | 'cubic',
+            # simulator.py:774-775); the device interpolation is the linear one only
+            raise NotImplementedError(
+                f"wtk_interp_type = {self.wtk_interp_type!r}: wind samples are interpolated linearly on the "
+                "device (lattice: bilinear; scattered points: Delaunay + barycentric = griddata 'linear'); "
+                "interpolate with scipy yourself and inject (rows, cols) rasters for 'nearest' / 'cubic'")
         if self.sim_mode.lower() == 'snapshot' and len(out) != 1:
             raise ValueError('snapshot mode takes exactly one wind entry')
         return out
@@ -266,8 +273,14 @@ class Simulator(Config):
             # samples on a regular lattice (x_km[nx], y_km[ny], arrays (ny, nx)) or at scattered points
             # (x_km[npts], y_km[npts], arrays (npts,)): the reference's griddata, simulator.py:765-776
             if np.ndim(ws) == 1 and np.size(item['x_km']) == np.size(ws) == np.size(item['y_km']):
-                return interpolate_wind_scattered(item['x_km'], item['y_km'], ws, wd,
-                                                  self.gridsize, self.resolution)
+                ws_d, wd_d = interpolate_wind_scattered(item['x_km'], item['y_km'], ws, wd,
+                                                        self.gridsize, self.resolution)
+                if bool(torch.isnan(ws_d).any()):
+                    # griddata's behaviour (cells outside the samples' convex hull are NaN); the reference
+                    # prints rather than raises when NaNs turn up (simulator.py:286)
+                    print(f"{item['case_id']}: NANs in the interpolated wind (raster cells outside the convex "
+                          'hull of the wind samples); their updraft is 0')
+                return ws_d, wd_d
             return interpolate_wind_lattice(item['x_km'], item['y_km'], ws, wd,
                                             self.gridsize, self.resolution)
         ws = to_dev(ws, torch.float64)
@@ -385,6 +398,17 @@ class Simulator(Config):
         dist.broadcast(t, src=src)
         return t.cpu().numpy()
 
+    def _allreduce_sum_int64(self, values):
+        """Sum over the ranks of an int64 vector, on every rank."""
+        import torch.distributed as dist
+        arr = np.asarray(values, dtype=np.int64)
+        if not (self._dist_on() and dist.get_world_size() > 1):
+            return arr
+        dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
+        t = torch.from_numpy(arr.copy()).to(dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.cpu().numpy()
+
     # device-resident forms of load_updrafts / get_directional_potential: the public methods
     # keep the reference's numpy-in / numpy-out contract, the stepper takes these
     def _load_updrafts_dev(self, case_id):
@@ -452,6 +476,9 @@ class Simulator(Config):
             from .distributed import shard_range
             lo, hi = shard_range(len(starts), self._rank(), self._world())
         my_starts = to_dev(starts[lo:hi], torch.int32)
+        # the largest share of any rank (shard sizes differ by one): whether the counts are kept in 64 bits
+        # must not depend on the rank, or the ranks would meet in the reduce with different dtypes
+        widest_share = -(-len(starts) // self._world()) if sharded else len(starts)
 
         # (case, realisation) items are independent: like the reference's loop
         # they are prepared in order on this thread (file cache, reseeding), then
@@ -477,16 +504,20 @@ class Simulator(Config):
             id_str = self._get_id_string(case_id, real_id)
             start_time = time.time()
             with torch.cuda.stream(torch.cuda.Stream()):
-                batch = self._step_case(my_starts, lo, fields, seed, use_table)
+                batch = self._step_case(my_starts, lo, fields, seed, use_table, widest_share)
                 torch.cuda.current_stream().synchronize()
                 print(f'{id_str}: Simulating {hi - lo} tracks..took {_elapsed(start_time)}',
                       flush=True)
                 if self.save_tracks:
                     # (inside the stream's scope: long trajectories are stepped again range by range while written)
                     need = sum(b.total_points for b in batch.parts) * 4
+                    if sharded:
+                        # the limit is the merged file's, and every rank must reach the same verdict (a rank
+                        # that raised alone would leave the others waiting in _write_tracks' barrier)
+                        need = int(self._allreduce_sum_int64([need])[0])
                     if need > float(self.max_tracks_file_gb) * 2 ** 30:
                         raise ValueError(
-                            f'{id_str}: the trajectories of these {hi - lo} tracks are {need / 2 ** 30:.1f} GiB '
+                            f'{id_str}: the trajectories of these {len(starts)} tracks are {need / 2 ** 30:.1f} GiB '
                             f'(Sum lengths x 4 B; max_tracks_file_gb = {self.max_tracks_file_gb:g}): on fields where '
                             'tracks wander to max_moves run with save_tracks=False, or raise max_tracks_file_gb')
                     fname = self._get_tracks_fname(case_id, real_id, self.mode_data_dir)
@@ -507,7 +538,12 @@ class Simulator(Config):
                 self.last_stats[key] = batch.stats
 
         if workers == 1:
-            collect(run(it) for it in prepare())
+            try:
+                collect(run(it) for it in prepare())
+            finally:
+                # the stepper's scratch (13-15 GB with the pair / fine tables at 5000 x 6000) is cached per
+                # thread between calls; K4, K5 and the next run size their own buffers from the free HBM
+                movmodel.release_workspaces()
         else:
             # bounded pipeline: at most `workers` prepared items (device rasters) alive
             from concurrent.futures import ThreadPoolExecutor, wait, FIRST_COMPLETED
@@ -520,7 +556,7 @@ class Simulator(Config):
                         collect(f.result() for f in done)
                 collect(f.result() for f in pending)
 
-    def _step_case(self, my_starts, lo, fields, seed, use_table):
+    def _step_case(self, my_starts, lo, fields, seed, use_table, widest_share=None):
         """The tracks of one (case, realisation) on this rank.  The presence histogram is uint32 (the
         reference's int16 wraps at 32 767, movmodel.py:415): a trap cell of the solved 10 m field takes
         ~1e9 visits per 100k tracks, so more than `hist_safe_tracks` tracks are stepped in sub-batches whose
@@ -530,6 +566,7 @@ class Simulator(Config):
         n = int(my_starts.shape[0])
         step = max(1, int(self.hist_safe_tracks))
         parts, wide, stats = [], None, None
+        widen = max(n, int(widest_share or 0)) > step
         for t0 in range(0, max(n, 1), step):
             sub = my_starts[t0:t0 + step]
             b = movmodel.simulate_tracks(
@@ -544,7 +581,7 @@ class Simulator(Config):
                     f'{int(sub.shape[0])} tracks (a cell passed 2^32 - 1): lower Config.hist_safe_tracks '
                     f'(now {self.hist_safe_tracks})')
             parts.append(b)
-            if n > step:
+            if widen:
                 h64 = b.hist.view(torch.int32).to(torch.int64) & 0xFFFFFFFF
                 wide = h64 if wide is None else wide.add_(h64)
                 b.hist = None
@@ -624,7 +661,7 @@ class Simulator(Config):
         """The numeric part of plot_presence_map (simulator.py:518-546): returns
         the f32 summary map and writes summary_presence.npy."""
         krad = presence.presence_kernel_radius(radius, self.resolution, self.gridsize)
-        dev = torch.device('cuda', torch.cuda.current_device())
+        dev = self._presence_device()
         summary = torch.zeros(self.gridsize, dtype=torch.float64, device=dev)
         self.case_presence = {}
         for case_id in self.my_case_ids():
@@ -644,6 +681,10 @@ class Simulator(Config):
             np.save(os.path.join(self.mode_data_dir, 'summary_presence.npy'), out)
         self._barrier()
         return out
+
+    @staticmethod
+    def _presence_device():
+        return torch.device('cuda', torch.cuda.current_device())
 
     # ---------------------------------------------------------- multi-GPU
     @staticmethod

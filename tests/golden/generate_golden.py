@@ -498,7 +498,7 @@ def g11_wander(ntracks=64, procs=8):
     about half of the reference's tracks never leave the raster -- they reach a basin of
     the potential field whose outlet the f32 field does not resolve, circle there and stop
     at max_moves = 300 000 (movmodel.py:277,285).  Pins that regime (the one the 10 m
-    configs live in: tools/probe_traps.py) to the reference: potential, lengths, end cells
+    configs live in: tools/attic/probe_traps.py) to the reference: potential, lengths, end cells
     and the sha256 over every point of the 64 tracks."""
     rows, cols, res = 1000, 1200, 50.
     print(f'G11 wandering regime: {rows}x{cols} @50 m, {ntracks} tracks, seed 30 (reference, slow)')

@@ -18,6 +18,14 @@ def build(mode, out_dir, run_name):
                 track_direction=0.)
     if mode == 'uniform':
         return Simulator(Config(**base), terrain='synthetic')
+    if mode == 'subbatch':
+        # 301 tracks, at most 150 per uint32 histogram: with two ranks rank 0 steps 151 (two sub-batches, its
+        # counts widen to 64 bits) and rank 1 exactly 150 -- the ranks must still meet in the same collectives
+        return Simulator(Config(hist_safe_tracks=150, **base), terrain='synthetic')
+    if mode == 'fileguard':
+        # ~301 tracks x ~70 points x 4 B = ~80 KB merged; the limit sits between one rank's share and the
+        # merged file: every rank must refuse (a rank raising alone would leave its peer in a barrier)
+        return Simulator(Config(max_tracks_file_gb=float(os.environ['SSRS_TEST_FILE_GB']), **base), terrain='synthetic')
     if mode == 'unseeded':            # uniform mode without a seed: the ranks must agree on rank 0's draws
         base['sim_seed'] = -1
         return Simulator(Config(**base), terrain='synthetic')
@@ -47,6 +55,16 @@ def main():
         from datetime import timedelta
         dist.init_process_group('gloo', rank=rank, world_size=world, timeout=timedelta(seconds=180))
     sim = build(mode, out_dir, f'{mode}_w{world}')
+    if mode == 'fileguard':
+        try:
+            sim.simulate_tracks()
+        except ValueError as exc:
+            print('REFUSED:', exc, flush=True)
+            if world > 1:
+                dist.barrier()          # every rank got here: nobody is parked in a collective
+                dist.destroy_process_group()
+            sys.exit(7)
+        sys.exit(0)
     sim.simulate_tracks()
     if mode == 'unseeded':
         import json

@@ -131,7 +131,7 @@ def test_g10_stepper_on_the_hip_potential(gpu, g10):
 def test_g11_wandering_tracks_on_the_reference_potential_are_bit_exact(gpu, g11):
     """G11: about half of the reference's own tracks circle in a basin of its potential field
     until max_moves = 300 000.  Every stepper path reproduces all 64 tracks (9.6e6 points) --
-    this is the regime BASELINE's 10 m configs live in (tools/probe_traps.py)."""
+    this is the regime BASELINE's 10 m configs live in (tools/attic/probe_traps.py)."""
     from ssrs_amd import layers, movmodel
     shape = g11['shape']
     upd = layers.get_above_threshold_speed(g11['orograph_f32'], 0.75)

@@ -25,9 +25,9 @@ def _free_port():
     return port
 
 
-def _run(world, out_dir, mode):
+def _run(world, out_dir, mode, expect_rc=0, env_extra=None):
     port = str(_free_port())
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', **(env_extra or {}))
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, 'mp_simulator_worker.py'), str(r), str(world),
                                port, out_dir, mode], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
              for r in range(world)]
@@ -43,11 +43,13 @@ def _run(world, out_dir, mode):
                 p.kill()
                 p.wait()
     for r, (p, o) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0, f'rank {r} failed:\n{o[-3000:]}'
-    return os.path.join(out_dir, f'{mode}_w{world}', 'data', 'uniform' if mode == 'unseeded' else mode)
+        assert p.returncode == expect_rc, f'rank {r} exited with {p.returncode}:\n{o[-3000:]}'
+    if expect_rc:
+        return outs
+    return os.path.join(out_dir, f'{mode}_w{world}', 'data', mode if mode in ('snapshot', 'seasonal') else 'uniform')
 
 
-@pytest.mark.parametrize('mode', ['uniform', 'snapshot', 'seasonal'])
+@pytest.mark.parametrize('mode', ['uniform', 'snapshot', 'seasonal', 'subbatch'])
 def test_two_ranks_equal_one_rank(gpu, tmp_path, mode):
     one = _run(1, str(tmp_path), mode)
     two = _run(2, str(tmp_path), mode)
@@ -92,3 +94,23 @@ def test_unseeded_shards_step_under_one_seed(gpu, tmp_path):
     one = movmodel.simulate_tracks(0., starts, upd.shape, 1, 1., upd, pot, seed=seeds[0][0][1], want_tracks=True)
     for a, b in zip(one.tracks(), tracks):
         assert np.array_equal(a, b)
+
+
+def test_file_size_guard_is_agreed_on_by_all_ranks(gpu, tmp_path):
+    """max_tracks_file_gb is the limit of the MERGED <id>_tracks.pkl: with a limit between one rank's share
+    and the whole every rank refuses together (a rank raising alone left the others in
+    _write_tracks' barrier until the collective timed out), and one process refuses the same run."""
+    import re
+    one = _run(1, str(tmp_path), 'uniform')
+    with open(glob.glob(os.path.join(one, '*_tracks.pkl'))[0], 'rb') as f:
+        tracks = pickle.load(f)
+    total = sum(len(t) for t in tracks) * 4
+    half = sum(len(t) for t in tracks[:151]) * 4            # rank 0's share of 301 tracks
+    assert half < 0.75 * total
+    limit_gb = 0.875 * total / 2 ** 30                      # above either share, below the merged file
+    assert half < limit_gb * 2 ** 30 < total
+    for world in (1, 2):
+        outs = _run(world, str(tmp_path), 'fileguard', expect_rc=7, env_extra={'SSRS_TEST_FILE_GB': repr(limit_gb)})
+        for o in outs:
+            m = re.search(r'REFUSED: .*these 301 tracks are', o)
+            assert m, o[-2000:]

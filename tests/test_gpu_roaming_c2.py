@@ -95,3 +95,75 @@ def test_uncapped_batch_properties_at_c2(c2_field):
     # and every track that finished under the cap has the same length uncapped
     done = cl - 1 < CAP
     assert np.array_equal(cl[done], lengths[done])
+
+
+def test_uncapped_roaming_tracks_vs_oracle_at_c2(c2_field):
+    """The regime the headline spends 99 % of its time in, against the oracle WITHOUT a cap (VERDICT r3 item 1;
+    /root/reference/ssrs/movmodel.py:285-317): the 20 000-track batch runs to max_moves = 7.5e6 on the GPU --
+    ~130 pair-table launches of 65 536 steps, the stop flag, the periodic re-deal -- and eight contiguous id
+    ranges of 64 tracks (finishers, tracks that leave a basin after 1e5..7e6 moves, tracks at max_moves) are
+    stepped uncapped by the C oracle under their global ids (~1.3e9 steps): lengths and end cells must be equal.
+    Then the same batch with the re-deal after EVERY settled batch and with none at all: identical integers."""
+    import os
+    from ssrs_amd import movmodel
+    from oracle import c_oracle
+    f = c2_field
+    n = 20_000
+    starts = f['starts'][:n]
+    mm = SHAPE[0] // 2 * (SHAPE[1] // 2)
+    got = movmodel.simulate_tracks(0., starts, SHAPE, 1, 1., f['upd'], f['pot'], seed=30)
+    st = got.stats
+    assert st['roam_launches'] > 50 and st['roam_shuffles'] > 0, st
+    lengths = got.lengths.cpu().numpy()
+    ends = got.ends.cpu().numpy()
+    ids = np.concatenate([np.arange(b, b + 64) for b in range(137, n, n // 8)][:8])
+    ref = c_oracle.simulate_tracks(0., starts[ids], SHAPE, 1, 1., f['upd_h'], f['pot_h'], seed=30, want_traj=False,
+                                   want_hist=False, track_ids=ids)
+    sub = lengths[ids].astype(np.int64) - 1
+    late = int(np.sum((sub > CAP) & (sub < mm)))
+    assert int(np.sum(sub == mm)) >= 64 and late >= 16, (int(np.sum(sub == mm)), late)     # the sample holds the regime
+    assert np.array_equal(lengths[ids], ref['lengths'])
+    assert np.array_equal(ends[ids], ref['ends'])
+    assert ref['steps'] > 1.0e9
+    for shuffle in ('1', '0'):
+        os.environ['SSRS_TRACKS_ROAM_SHUFFLE'] = shuffle
+        try:
+            alt = movmodel.simulate_tracks(0., starts, SHAPE, 1, 1., f['upd'], f['pot'], seed=30)
+        finally:
+            del os.environ['SSRS_TRACKS_ROAM_SHUFFLE']
+        assert (alt.stats['roam_shuffles'] > st['roam_shuffles']) if shuffle == '1' else (alt.stats['roam_shuffles'] == 0), \
+            (shuffle, alt.stats['roam_shuffles'], st['roam_shuffles'])
+        assert torch.equal(alt.lengths, got.lengths) and torch.equal(alt.ends, got.ends) and torch.equal(alt.hist, got.hist), shuffle
+
+
+def test_config2_share_125k_tracks_on_the_solved_field(c2_field):
+    """One GPU's share of BASELINE configs[2] (1 M tracks over 8 GPUs = 125 000 per GPU, ids 0..124 999 = rank 0's
+    shard) on K5's field at full size, uncapped.  No oracle follows 3.3e11 steps; what holds at this size: the
+    histogram counts every point once, every track ends on the raster's edge or at max_moves exactly, and the
+    tracks of the capped oracle run that FINISHED under the cap (4 000-track prefix, the host's threads, seconds)
+    have the same length and end cell here."""
+    from ssrs_amd import movmodel
+    from oracle import c_oracle
+    f = c2_field
+    n = 125_000
+    np.random.seed(30)
+    r, c = movmodel.get_starting_indices(1_000_000, (5, 55, 1, 2), 'random', (60., 50.), RES)
+    starts = np.stack([r, c], 1).astype(np.int32)[:n]
+    got = movmodel.simulate_tracks(0., starts, SHAPE, 1, 1., f['upd'], f['pot'], seed=30)
+    lengths = got.lengths.cpu().numpy().astype(np.int64)
+    ends = got.ends.cpu().numpy()
+    mm = SHAPE[0] // 2 * (SHAPE[1] // 2)
+    hist = got.hist.cpu().numpy().view(np.uint32)
+    assert int(hist.sum(dtype=np.uint64)) == got.stats['total_steps'] + n == int(lengths.sum())
+    assert got.stats['roam_launches'] > 50 and got.stats['total_steps'] > 2.5e11
+    on_edge = (ends[:, 0] == 0) | (ends[:, 0] == SHAPE[0] - 1) | (ends[:, 1] == 0) | (ends[:, 1] == SHAPE[1] - 1)
+    assert np.all(on_edge | (lengths == mm + 1))
+    assert 0.2 < float(np.mean(lengths == mm + 1)) < 0.45
+    m = 4_000
+    ref = c_oracle.simulate_tracks(0., starts[:m], SHAPE, 1, 1., f['upd_h'], f['pot_h'], seed=30, want_traj=False,
+                                   want_hist=False, max_moves=CAP)
+    done = ref['lengths'].astype(np.int64) - 1 < CAP
+    assert 0.4 < float(np.mean(done)) < 0.75
+    assert np.array_equal(lengths[:m][done], ref['lengths'][done])
+    assert np.array_equal(ends[:m][done], ref['ends'][done])
+    assert np.all(lengths[:m][~done] - 1 >= CAP)

@@ -3,7 +3,7 @@ probes of it (no Philox, no table gather, neither; SSRS_HIP_LIB picks the librar
 each) on the bench workload: 16 384 tracks (one wave per CU: the latency of a lone wave's step)
 and 100 000 tracks (the bench batch).  Results of the probe libraries are wrong on purpose."""
 import os, sys, subprocess, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 1 and sys.argv[1] == 'child':
     sys.path.insert(0, ROOT)
     import numpy as np, torch

@@ -1,7 +1,7 @@
 """A/B of the double pairwise aggregation experiment (SSRS_AMG_DOUBLE, profiles/r01_notes.md): which field
-property breaks it?  python tools/probe_double.py"""
+property breaks it?  python tools/attic/probe_double.py"""
 import os, sys, warnings
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from ssrs_amd import layers
 from ssrs_amd.potential import solve_potential

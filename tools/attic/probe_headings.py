@@ -1,7 +1,7 @@
 """C2 workload for other headings: linear ramp potential along the heading (stand-in), starts
 in a band at the upstream edge.  How do the coherent schedule and the binning cope?"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from ssrs_amd import layers, movmodel
 from ssrs_amd.synthetic import synthetic_dem

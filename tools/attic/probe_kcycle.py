@@ -1,6 +1,6 @@
-"""C2 potential solve with K-cycle depths: iterations and time (python tools/probe_kcycle.py 0 1 2 3)."""
+"""C2 potential solve with K-cycle depths: iterations and time (python tools/attic/probe_kcycle.py 0 1 2 3)."""
 import os, sys, time, warnings
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from ssrs_amd import layers
 from ssrs_amd.potential import solve_potential

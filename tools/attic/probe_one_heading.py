@@ -1,6 +1,6 @@
-"""One oblique-heading batch at C2 for rocprofv3: python tools/probe_one_heading.py 45"""
+"""One oblique-heading batch at C2 for rocprofv3: python tools/attic/probe_one_heading.py 45"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from ssrs_amd import layers, movmodel
 from ssrs_amd.synthetic import synthetic_dem

@@ -3,7 +3,7 @@ threads / HIP streams, the way ssrs_amd.Simulator pipelines its cases.  bench.py
 stays sequential (one batch at a time); this shows what one GPU sustains when several
 independent 100k-track batches are available."""
 import os, sys, time, threading
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from ssrs_amd import layers, movmodel
 from ssrs_amd.synthetic import synthetic_dem, ramp_potential

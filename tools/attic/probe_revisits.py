@@ -1,7 +1,7 @@
 """How many distinct cells does a track visit within one launch (512 steps) once it is
 wandering in the solved C2 field?"""
 import os, sys, time, warnings
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from ssrs_amd import layers, movmodel
 from ssrs_amd.potential import solve_potential

@@ -1,7 +1,7 @@
 """Solved potential on a 2000 x 2400 synthetic raster, 20k tracks: how often does a step
 take the exact sequence?"""
 import os, sys, time, warnings
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from ssrs_amd import layers, movmodel
 from ssrs_amd.potential import solve_potential

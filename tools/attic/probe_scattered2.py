@@ -1,7 +1,7 @@
 """Wandering regime (smooth 10-m terrain, solved potential, tracks up to max_moves): what
 bounds a step -- the table gather, the histogram atomic, or neither?"""
 import os, sys, time, warnings
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from ssrs_amd import layers, movmodel
 from ssrs_amd.potential import solve_potential

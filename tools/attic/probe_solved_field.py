@@ -3,7 +3,7 @@ Solve the C2 potential at several tolerances, count the strict interior minima /
 f32 field (the exact solution is discrete-harmonic: none) and step a batch through each field.
 usage: probe_solved_field.py [rows cols [ntracks [cap]]]"""
 import os, sys, time, warnings
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import torch.nn.functional as F
 from ssrs_amd import layers, movmodel

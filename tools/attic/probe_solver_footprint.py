@@ -1,6 +1,6 @@
 """K5 at C2: set-up time, solve time, iterations and the bytes of workspace really used."""
 import os, sys, time, warnings
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from ssrs_amd import layers
 from ssrs_amd.potential import solve_potential

@@ -1,6 +1,6 @@
 """C2 workload: histogram-only call vs the two-pass trajectory call (Simulator default)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from ssrs_amd import layers, movmodel
 from ssrs_amd.synthetic import synthetic_dem, ramp_potential

@@ -2,7 +2,7 @@
 (default tolerance), 20k tracks capped at 60000 steps; for a few capped tracks: bounding box of
 the second half of the trajectory, live fraction and f32 potential levels inside it."""
 import os, sys, time, warnings
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from ssrs_amd import layers, movmodel
 from ssrs_amd.potential import solve_potential

@@ -1,7 +1,7 @@
 """Does a neighbouring snapshot's potential help as initial guess?  2000 x 2400 synthetic
 raster, wind changed from 10 m/s @ 270 deg to the values below."""
 import os, sys, time, warnings
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from ssrs_amd import layers
 from ssrs_amd.potential import solve_potential

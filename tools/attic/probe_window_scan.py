@@ -2,7 +2,7 @@
 tolerance, 2048 tracks from the window's southern band; reports the share of tracks that take
 more than 10 x rows steps.  usage: probe_window_scan.py [rows cols]"""
 import os, sys, time, warnings
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from ssrs_amd import layers, movmodel
 from ssrs_amd.potential import solve_potential

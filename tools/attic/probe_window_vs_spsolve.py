@@ -2,7 +2,7 @@
 comes from oracle.solve_potential = assemble + SuperLU, staged in scratch/ by the build container):
 field difference, and the same tracks stepped through both fields."""
 import os, sys, time, warnings
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from ssrs_amd import layers, movmodel
 from ssrs_amd.potential import solve_potential

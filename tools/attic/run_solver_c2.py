@@ -1,6 +1,6 @@
 """Solve the C2 potential once (for rocprofv3): 5000 x 6000 synthetic raster at 10 m."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, warnings
 from ssrs_amd import layers
 from ssrs_amd.potential import solve_potential
