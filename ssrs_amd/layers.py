@@ -127,15 +127,22 @@ def get_above_threshold_speed(in_array, threshold):
 
 
 def updraft_from_dem(z_mat, res, wspeed, wdirn, threshold=None, min_updraft_val=0.,
-                     want_orograph=True):
+                     want_orograph=True, out=None):
     """Fused uniform-mode raster: DEM -> (orograph f32, usable f64 | None).
-    One HBM pass (8-12 B/cell + outputs), no trig; see DESIGN.md K1."""
+    One HBM pass (8-12 B/cell + outputs), no trig; see DESIGN.md K1.
+    `out` = (orograph f32, usable f64) CUDA tensors to write into (either may be None)."""
     dem = float_dev(z_mat)
     rows, cols = _shape2(dem)
-    oro = torch.empty((rows, cols), dtype=torch.float32, device=dem.device) \
-        if want_orograph else None
-    use = torch.empty((rows, cols), dtype=torch.float64, device=dem.device) \
-        if threshold is not None else None
+    oro = use = None
+    if out is not None:
+        oro, use = out
+        for t, dt in ((oro, torch.float32), (use, torch.float64)):
+            if t is not None and not (t.is_cuda and t.dtype == dt and tuple(t.shape) == (rows, cols) and t.is_contiguous()):
+                raise ValueError(f'out tensors must be contiguous CUDA ({rows}, {cols}) float32 / float64')
+    if oro is None and want_orograph:
+        oro = torch.empty((rows, cols), dtype=torch.float32, device=dem.device)
+    if use is None and threshold is not None:
+        use = torch.empty((rows, cols), dtype=torch.float64, device=dem.device)
     nat.check(nat.lib().ssrs_updraft_from_dem(
         nat.ptr(dem), ftype(dem), C.c_double(res), C.c_double(wspeed), C.c_double(wdirn),
         C.c_double(min_updraft_val), nat.ptr(oro),

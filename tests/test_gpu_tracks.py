@@ -973,6 +973,36 @@ def test_roam_launches_while_tracks_still_wait_for_their_release(gpu):
         assert np.array_equal(hist, ref['hist']), switch
 
 
+@pytest.mark.parametrize('dirn', [0., 180., 90., 315.])
+def test_pair_table_launch_with_tracks_on_the_boundary_rows(gpu, dirn):
+    """The one memory fault of round 3 (profiles/r03_notes.md section 2, found by the soak): k_step_roam issues the
+    NEXT pair-table gather before it knows whether the lane steps at all, and a lane standing on a boundary cell
+    (waiting for its release on row 0 / 1 / rows - 2 / rows - 1, or just finished there) formed an index up to two
+    rows outside the raster.  The index is clamped into the table now (tracks.hip, `cb = min(cell_b, last_cell)`).
+    Here every track STARTS on the outer two rings of a tiny raster, launches are 16 steps long and the batch is
+    flagged scattered, so pair-table launches start while most tracks still stand on those cells."""
+    from ssrs_amd import movmodel
+    from oracle import c_oracle
+    rows, cols = 9, 150
+    rng = np.random.default_rng(int(dirn) + 5)
+    upd = np.abs(rng.normal(0.8, 0.6, (rows, cols)))
+    pot = (1000. * (1 - np.arange(rows)[:, None] / (rows - 1.)) + rng.normal(0, 30., (rows, cols))).astype(np.float32)
+    n = 9000
+    ring_r = rng.choice([0, 1, rows - 2, rows - 1], n)
+    ring_c = rng.choice([0, 1, cols - 2, cols - 1], n)
+    on_row = rng.random(n) < 0.7
+    starts = np.stack([np.where(on_row, ring_r, rng.integers(0, rows, n)),
+                       np.where(on_row, rng.integers(0, cols, n), ring_c)], 1)
+    ref = c_oracle.simulate_tracks(dirn, starts, (rows, cols), 1, 1., upd, pot, seed=11, want_traj=False)
+    res = movmodel.simulate_tracks(dirn, starts, (rows, cols), 1, 1., upd, pot, seed=11, steps_per_launch=16,
+                                   use_table=True, thr=True, scattered=True)
+    assert res.stats['roam_launches'] > 0, res.stats
+    lens, ends, hist = _no_traj_result(res)
+    assert np.array_equal(lens, ref['lengths'])
+    assert np.array_equal(ends, ref['ends'])
+    assert np.array_equal(hist, ref['hist'])
+
+
 def test_block_windows_when_nearly_every_track_is_trapped(gpu):
     """8192 tracks (the lists have no spare slots), a wide trough that catches most of them: the
     padded deal of the wander sort does not fit and falls back to the dense one (blocks may then mix
