@@ -332,12 +332,17 @@ __global__ __launch_bounds__(kBlock) void k_unpack_coarse(const unsigned long lo
 }
 
 // ---- cycle kernels --------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_jacobi_first(const double *__restrict__ dinv,
-                                                        const double *__restrict__ b, int n,
-                                                        double *__restrict__ x, double w)
+__global__ __launch_bounds__(kBlock) void k_jacobi_first(const cv_t *__restrict__ dinv,
+                                                        const cv_t *__restrict__ b, int n,
+                                                        cv_t *__restrict__ x, double w)
 {
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
-        x[i] = w * dinv[i] * b[i];
+        x[i] = static_cast<cv_t>(w * dinv[i] * b[i]);
+}
+
+__global__ __launch_bounds__(kBlock) void k_to_cv(const double *__restrict__ a, int n, cv_t *__restrict__ out)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) out[i] = static_cast<cv_t>(a[i]);
 }
 
 // Four lanes per row for the large CSR levels: a thread-per-row walk reads val/col
@@ -347,12 +352,12 @@ __global__ __launch_bounds__(kBlock) void k_jacobi_first(const double *__restric
 constexpr int kRowLanes = 4;
 template <class V>
 __device__ __forceinline__ double row_dot4(const int *__restrict__ rowptr, const int *__restrict__ col,
-                                           const V *__restrict__ val, const double *__restrict__ x,
+                                           const V *__restrict__ val, const cv_t *__restrict__ x,
                                            int row, int sub)
 {
     double ax = 0.0;
     const int end = rowptr[row + 1];
-    for (int p = rowptr[row] + sub; p < end; p += kRowLanes) ax += val[p] * x[col[p]];
+    for (int p = rowptr[row] + sub; p < end; p += kRowLanes) ax += static_cast<double>(val[p]) * x[col[p]];
     ax += __shfl_xor(ax, 1);
     ax += __shfl_xor(ax, 2);
     return ax;
@@ -365,7 +370,7 @@ __device__ __forceinline__ double row_dot4(const int *__restrict__ rowptr, const
 constexpr int kRowsPerGroup = 4;
 template <class V>
 __device__ __forceinline__ void rows_dot4(const int *__restrict__ rowptr, const int *__restrict__ col,
-                                          const V *__restrict__ val, const double *__restrict__ x,
+                                          const V *__restrict__ val, const cv_t *__restrict__ x,
                                           const long long (&row)[kRowsPerGroup], int n, int sub,
                                           double (&ax)[kRowsPerGroup])
 {
@@ -409,10 +414,10 @@ template <class V>
 __global__ __launch_bounds__(kBlock) void k_jacobi4(const int *__restrict__ rowptr,
                                                    const int *__restrict__ col,
                                                    const V *__restrict__ val,
-                                                   const double *__restrict__ dinv,
-                                                   const double *__restrict__ b,
-                                                   const double *__restrict__ x, int n,
-                                                   double *__restrict__ xn, double w)
+                                                   const cv_t *__restrict__ dinv,
+                                                   const cv_t *__restrict__ b,
+                                                   const cv_t *__restrict__ x, int n,
+                                                   cv_t *__restrict__ xn, double w)
 {
     const int sub = threadIdx.x % kRowLanes;
     const long long groups = static_cast<long long>(gridDim.x) * (kBlock / kRowLanes);
@@ -426,7 +431,7 @@ __global__ __launch_bounds__(kBlock) void k_jacobi4(const int *__restrict__ rowp
         rows_dot4(rowptr, col, val, x, row, n, sub, ax);
 #pragma unroll
         for (int u = 0; u < kRowsPerGroup; ++u)
-            if (sub == 0 && row[u] < n) xn[row[u]] = x[row[u]] + w * dinv[row[u]] * (b[row[u]] - ax[u]);
+            if (sub == 0 && row[u] < n) xn[row[u]] = static_cast<cv_t>(x[row[u]] + w * dinv[row[u]] * (b[row[u]] - ax[u]));
     }
 }
 
@@ -434,9 +439,9 @@ template <class V>
 __global__ __launch_bounds__(kBlock) void k_residual4(const int *__restrict__ rowptr,
                                                      const int *__restrict__ col,
                                                      const V *__restrict__ val,
-                                                     const double *__restrict__ b,
-                                                     const double *__restrict__ x, int n,
-                                                     double *__restrict__ r)
+                                                     const cv_t *__restrict__ b,
+                                                     const cv_t *__restrict__ x, int n,
+                                                     cv_t *__restrict__ r)
 {
     const int sub = threadIdx.x % kRowLanes;
     const long long groups = static_cast<long long>(gridDim.x) * (kBlock / kRowLanes);
@@ -449,7 +454,7 @@ __global__ __launch_bounds__(kBlock) void k_residual4(const int *__restrict__ ro
         rows_dot4(rowptr, col, val, x, row, n, sub, ax);
 #pragma unroll
         for (int u = 0; u < kRowsPerGroup; ++u)
-            if (sub == 0 && row[u] < n) r[row[u]] = b[row[u]] - ax[u];
+            if (sub == 0 && row[u] < n) r[row[u]] = static_cast<cv_t>(b[row[u]] - ax[u]);
     }
 }
 
@@ -457,15 +462,15 @@ template <class V>
 __global__ __launch_bounds__(kBlock) void k_jacobi(const int *__restrict__ rowptr,
                                                   const int *__restrict__ col,
                                                   const V *__restrict__ val,
-                                                  const double *__restrict__ dinv,
-                                                  const double *__restrict__ b,
-                                                  const double *__restrict__ x, int n,
-                                                  double *__restrict__ xn, double w)
+                                                  const cv_t *__restrict__ dinv,
+                                                  const cv_t *__restrict__ b,
+                                                  const cv_t *__restrict__ x, int n,
+                                                  cv_t *__restrict__ xn, double w)
 {
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         double ax = 0.0;
-        for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) ax += val[p] * x[col[p]];
-        xn[i] = x[i] + w * dinv[i] * (b[i] - ax);
+        for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) ax += static_cast<double>(val[p]) * x[col[p]];
+        xn[i] = static_cast<cv_t>(x[i] + w * dinv[i] * (b[i] - ax));
     }
 }
 
@@ -473,14 +478,14 @@ template <class V>
 __global__ __launch_bounds__(kBlock) void k_residual(const int *__restrict__ rowptr,
                                                     const int *__restrict__ col,
                                                     const V *__restrict__ val,
-                                                    const double *__restrict__ b,
-                                                    const double *__restrict__ x, int n,
-                                                    double *__restrict__ r)
+                                                    const cv_t *__restrict__ b,
+                                                    const cv_t *__restrict__ x, int n,
+                                                    cv_t *__restrict__ r)
 {
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         double ax = 0.0;
-        for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) ax += val[p] * x[col[p]];
-        r[i] = b[i] - ax;
+        for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) ax += static_cast<double>(val[p]) * x[col[p]];
+        r[i] = static_cast<cv_t>(b[i] - ax);
     }
 }
 
@@ -504,7 +509,7 @@ __global__ __launch_bounds__(kBlock) void k_val32(const int *__restrict__ rowptr
 // the five level-0 sweeps were two thirds of a V-cycle.  The CSR copy of level 0 is
 // still built: the aggregation and the Galerkin product read it.
 struct L0Stencil {
-    const double *rinv;       // 1 / cond, 0 where cond == 0 (then every link is 1e-8); the sign
+    const cv_t *rinv;         // 1 / cond, 0 where cond == 0 (then every link is 1e-8); the sign
                               // bit marks Dirichlet cells (saves nine byte loads per cell)
     const uint8_t *fixed;
     int rows, cols;
@@ -523,9 +528,10 @@ __global__ __launch_bounds__(kBlock) void k_l0_rinv(const double *__restrict__ c
 }
 
 // (A x)_i of the level-0 operator.  The weights are those of k_l0_fill up to rounding
-// (diagonal links are multiplied by 1/sqrt(2) instead of divided by sqrt(2)): this operator
-// only preconditions, what it must be is symmetric (w_ij is a function of ri + rj) and
-// diagonally dominant (diag = the sum of the same w_ij), which it is by construction.
+// (diagonal links are multiplied by 1/sqrt(2) instead of divided by sqrt(2), and the whole row is
+// evaluated in the cycle's precision): this operator only preconditions, what it must be is
+// symmetric (w_ij is a function of ri + rj) and diagonally dominant (diag = the sum of the same
+// w_ij), which it is by construction.
 constexpr double kInvFacDiag = 1.0 / 1.41421353816986083984375;
 
 // One wave = one row segment of 62 cells plus a halo lane on either side: every lane loads
@@ -533,35 +539,37 @@ constexpr double kInvFacDiag = 1.0 / 1.41421353816986083984375;
 // arrive by lane shuffles.  The kernels were bound by the number of load instructions (21
 // per cell with a thread-per-cell stencil: 0.66 ms per sweep at 5000 x 6000), not by bytes.
 constexpr int kL0Cols = 62;                                   // cells per wave
-__device__ __forceinline__ double l0_apply_wave(const L0Stencil &a, const double *__restrict__ x,
-                                                int r, int c, bool &centre, size_t &i)
+__device__ __forceinline__ cv_t l0_apply_wave(const L0Stencil &a, const cv_t *__restrict__ x,
+                                              int r, int c, bool &centre, size_t &i, cv_t &xi)
 {
     const int lane = threadIdx.x & 63;
     const bool col_ok = c >= 0 && c < a.cols;
-    double xv[3], sv[3];                                      // rows r-1, r, r+1 of this lane's column
+    const cv_t inf = static_cast<cv_t>(__builtin_inf());
+    cv_t xv[3], sv[3];                                        // rows r-1, r, r+1 of this lane's column
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         const int rr = r + d - 1;
         const bool ok = col_ok && rr >= 0 && rr < a.rows;
         const size_t j = static_cast<size_t>(ok ? rr : r) * a.cols + (col_ok ? c : 0);
-        xv[d] = ok ? x[j] : 0.0;
-        sv[d] = ok ? a.rinv[j] : __builtin_inf();             // +inf: outside the raster, no link
+        xv[d] = ok ? x[j] : static_cast<cv_t>(0);
+        sv[d] = ok ? a.rinv[j] : inf;                         // +inf: outside the raster, no link
     }
     i = static_cast<size_t>(r) * a.cols + (col_ok ? c : 0);
     centre = col_ok && lane >= 1 && lane <= kL0Cols;
-    const double si = sv[1], ri = si;
-    double diag = 0.0, off = 0.0;
+    xi = xv[1];
+    const cv_t si = sv[1], ri = fabs(si);
+    cv_t diag = 0, off = 0;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {                             // same order as before: rows south to north
         if (k == 4) continue;
         const int d = k / 3, dc = k % 3 - 1;
-        double sj = sv[d], xj = xv[d];
+        cv_t sj = sv[d], xj = xv[d];
         if (dc < 0) { sj = __shfl_up(sj, 1); xj = __shfl_up(xj, 1); }
         if (dc > 0) { sj = __shfl_down(sj, 1); xj = __shfl_down(xj, 1); }
-        const double rj = fabs(sj);
-        double w = (ri != 0.0 && rj != 0.0) ? 2.0 / (ri + rj) : 1e-08;
-        if (rj == __builtin_inf()) w = 0.0;
-        if (d != 1 && dc != 0) w = w * kInvFacDiag;
+        const cv_t rj = fabs(sj);
+        cv_t w = (ri != 0 && rj != 0) ? static_cast<cv_t>(2) / (ri + rj) : static_cast<cv_t>(1e-08);
+        if (rj == inf) w = 0;
+        if (d != 1 && dc != 0) w = w * static_cast<cv_t>(kInvFacDiag);
         diag += w;
         if (!signbit(sj)) off += w * xj;
     }
@@ -569,46 +577,48 @@ __device__ __forceinline__ double l0_apply_wave(const L0Stencil &a, const double
     return diag * xv[1] - off;
 }
 
-__global__ __launch_bounds__(kBlock) void k_l0_jacobi(L0Stencil a, const double *__restrict__ dinv,
-                                                     const double *__restrict__ b,
-                                                     const double *__restrict__ x,
-                                                     double *__restrict__ xn, double w)
+__global__ __launch_bounds__(kBlock) void k_l0_jacobi(L0Stencil a, const cv_t *__restrict__ dinv,
+                                                     const cv_t *__restrict__ b,
+                                                     const cv_t *__restrict__ x,
+                                                     cv_t *__restrict__ xn, cv_t w)
 {
     const int c = (static_cast<int>(blockIdx.x) * (kBlock / 64) + static_cast<int>(threadIdx.x >> 6)) * kL0Cols +
                   static_cast<int>(threadIdx.x & 63) - 1;
     bool centre;
     size_t i;
-    const double ax = l0_apply_wave(a, x, static_cast<int>(blockIdx.y), c, centre, i);
-    if (centre) xn[i] = x[i] + w * dinv[i] * (b[i] - ax);
+    cv_t xi;
+    const cv_t ax = l0_apply_wave(a, x, static_cast<int>(blockIdx.y), c, centre, i, xi);
+    if (centre) xn[i] = xi + w * dinv[i] * (b[i] - ax);
 }
 
-__global__ __launch_bounds__(kBlock) void k_l0_residual(L0Stencil a, const double *__restrict__ b,
-                                                       const double *__restrict__ x,
-                                                       double *__restrict__ r)
+__global__ __launch_bounds__(kBlock) void k_l0_residual(L0Stencil a, const cv_t *__restrict__ b,
+                                                       const cv_t *__restrict__ x,
+                                                       cv_t *__restrict__ r)
 {
     const int c = (static_cast<int>(blockIdx.x) * (kBlock / 64) + static_cast<int>(threadIdx.x >> 6)) * kL0Cols +
                   static_cast<int>(threadIdx.x & 63) - 1;
     bool centre;
     size_t i;
-    const double ax = l0_apply_wave(a, x, static_cast<int>(blockIdx.y), c, centre, i);
+    cv_t xi;
+    const cv_t ax = l0_apply_wave(a, x, static_cast<int>(blockIdx.y), c, centre, i, xi);
     if (centre) r[i] = b[i] - ax;
 }
 
 __global__ __launch_bounds__(kBlock) void k_restrict(const int *__restrict__ memptr,
                                                     const int *__restrict__ memidx,
-                                                    const double *__restrict__ r, int nc,
-                                                    double *__restrict__ bc)
+                                                    const cv_t *__restrict__ r, int nc,
+                                                    cv_t *__restrict__ bc)
 {
     for (int I = blockIdx.x * kBlock + threadIdx.x; I < nc; I += gridDim.x * kBlock) {
         double s = 0.0;                                   // members in index order: reproducible
         for (int p = memptr[I]; p < memptr[I + 1]; ++p) s += r[memidx[p]];
-        bc[I] = s;
+        bc[I] = static_cast<cv_t>(s);
     }
 }
 
 __global__ __launch_bounds__(kBlock) void k_prolong_add(const int *__restrict__ agg,
-                                                       const double *__restrict__ xc, int n,
-                                                       double *__restrict__ x)
+                                                       const cv_t *__restrict__ xc, int n,
+                                                       cv_t *__restrict__ x)
 {
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const int a = agg[i];
@@ -672,8 +682,8 @@ __global__ __launch_bounds__(kBlock) void k_gj_finish(const double *__restrict__
 // (coalesced), shuffle reduction.  (One thread per row walked 800 strided
 // loads serially and was ~40 % of a whole V-cycle at 500 x 600.)
 __global__ __launch_bounds__(kBlock) void k_dense_apply(const double *__restrict__ inv,
-                                                       const double *__restrict__ b, int n,
-                                                       double *__restrict__ x)
+                                                       const cv_t *__restrict__ b, int n,
+                                                       cv_t *__restrict__ x)
 {
     const int lane = threadIdx.x & 63;
     const int row = (blockIdx.x * kBlock + threadIdx.x) >> 6;
@@ -683,19 +693,40 @@ __global__ __launch_bounds__(kBlock) void k_dense_apply(const double *__restrict
     for (int j = lane; j < n; j += 64) s += r[j] * b[j];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-    if (lane == 0) x[row] = s;
+    if (lane == 0) x[row] = static_cast<cv_t>(s);
 }
 
-__global__ __launch_bounds__(kBlock) void k_axpy1(const double *__restrict__ a, int n, double *__restrict__ x)
+__global__ __launch_bounds__(kBlock) void k_axpy1(const cv_t *__restrict__ a, int n, cv_t *__restrict__ x)
 {
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) x[i] += a[i];
 }
 
-__global__ void k_copy(const double *__restrict__ a, double *__restrict__ b, size_t n)
+__global__ void k_copy(const cv_t *__restrict__ a, cv_t *__restrict__ b, size_t n)
 {
     for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n;
          i += static_cast<size_t>(gridDim.x) * blockDim.x)
         b[i] = a[i];
+}
+
+// the cycle's way in and out: b = rhs / sqrt(norm2) in the cycle's precision, out = x * sqrt(norm2) (M is linear)
+__device__ __forceinline__ double cycle_scale(const double *norm2)
+{
+    const double v = norm2 ? *norm2 : 1.0;
+    return (v > 0.0 && v < 1e300) ? sqrt(v) : 1.0;
+}
+__global__ void k_cycle_in(const double *__restrict__ rhs, const double *__restrict__ norm2, cv_t *__restrict__ b, size_t n)
+{
+    const double inv = 1.0 / cycle_scale(norm2);
+    for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * blockDim.x)
+        b[i] = static_cast<cv_t>(rhs[i] * inv);
+}
+__global__ void k_cycle_out(const cv_t *__restrict__ x, const double *__restrict__ norm2, double *__restrict__ out, size_t n)
+{
+    const double sc = cycle_scale(norm2);
+    for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * blockDim.x)
+        out[i] = static_cast<double>(x[i]) * sc;
 }
 
 // ---- K-cycle (Notay): two flexible-CG steps on a coarse level, each
@@ -708,13 +739,13 @@ struct KScalars {
 __global__ __launch_bounds__(kBlock) void k_spmv(const int *__restrict__ rowptr,
                                                 const int *__restrict__ col,
                                                 const double *__restrict__ val,
-                                                const double *__restrict__ x, int n,
-                                                double *__restrict__ y)
+                                                const cv_t *__restrict__ x, int n,
+                                                cv_t *__restrict__ y)
 {
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         double ax = 0.0;
         for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) ax += val[p] * x[col[p]];
-        y[i] = ax;
+        y[i] = static_cast<cv_t>(ax);
     }
 }
 
@@ -732,17 +763,17 @@ __device__ __forceinline__ double kblock_sum(double v, double *lds)
 }
 
 // up to three dot products a_k . b_k in one pass (NULL pairs are skipped)
-__global__ __launch_bounds__(kBlock) void k_dots(const double *a0, const double *b0,
-                                                const double *a1, const double *b1,
-                                                const double *a2, const double *b2, int n,
+__global__ __launch_bounds__(kBlock) void k_dots(const cv_t *a0, const cv_t *b0,
+                                                const cv_t *a1, const cv_t *b1,
+                                                const cv_t *a2, const cv_t *b2, int n,
                                                 KScalars *s)
 {
     __shared__ double lds[kBlock / 64];
     double d0 = 0.0, d1 = 0.0, d2 = 0.0;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        d0 += a0[i] * b0[i];
-        if (a1) d1 += a1[i] * b1[i];
-        if (a2) d2 += a2[i] * b2[i];
+        d0 += static_cast<double>(a0[i]) * b0[i];
+        if (a1) d1 += static_cast<double>(a1[i]) * b1[i];
+        if (a2) d2 += static_cast<double>(a2[i]) * b2[i];
     }
     d0 = kblock_sum(d0, lds);
     d1 = kblock_sum(d1, lds);
@@ -778,23 +809,23 @@ __global__ __launch_bounds__(kBlock) void k_kfinish(KScalars *s, int stage, int 
 }
 
 // r1 = b - f1 v1
-__global__ __launch_bounds__(kBlock) void k_kresid(const double *__restrict__ b,
-                                                  const double *__restrict__ v1, int n,
-                                                  const KScalars *s, double *__restrict__ r1)
+__global__ __launch_bounds__(kBlock) void k_kresid(const cv_t *__restrict__ b,
+                                                  const cv_t *__restrict__ v1, int n,
+                                                  const KScalars *s, cv_t *__restrict__ r1)
 {
     const double f1 = s->f1;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
-        r1[i] = b[i] - f1 * v1[i];
+        r1[i] = static_cast<cv_t>(b[i] - f1 * v1[i]);
 }
 
 // x = f1 c1 + f2 c2
-__global__ __launch_bounds__(kBlock) void k_kcombine(const double *__restrict__ c1,
-                                                    const double *__restrict__ c2, int n,
-                                                    const KScalars *s, double *__restrict__ x)
+__global__ __launch_bounds__(kBlock) void k_kcombine(const cv_t *__restrict__ c1,
+                                                    const cv_t *__restrict__ c2, int n,
+                                                    const KScalars *s, cv_t *__restrict__ x)
 {
     const double f1 = s->f1, f2 = s->f2;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
-        x[i] = f1 * c1[i] + f2 * c2[i];
+        x[i] = static_cast<cv_t>(f1 * c1[i] + f2 * c2[i]);
 }
 
 }  // namespace
@@ -852,6 +883,10 @@ int amg_setup(AmgHierarchy &h, const double *cond, const uint8_t *fixed, int row
         AMG_TAKE(rinv, double, n0);
         hipLaunchKernelGGL(k_l0_rinv, dim3(grid_for(n0)), dim3(kBlock), 0, st, cond, fixed, static_cast<size_t>(n0), rinv);
         h.l0_rinv = rinv;
+        cv_t *rinvc;
+        AMG_TAKE(rinvc, cv_t, n0);
+        hipLaunchKernelGGL(k_to_cv, dim3(grid_for(n0)), dim3(kBlock), 0, st, rinv, n0, rinvc);
+        h.l0_rinvc = rinvc;
         h.l0_fixed = fixed;
         h.l0_rows = rows;
         h.l0_cols = cols;
@@ -881,20 +916,22 @@ int amg_setup(AmgHierarchy &h, const double *cond, const uint8_t *fixed, int row
     for (int lev = 0;; ++lev) {
         const int n = L.n;
         AMG_TAKE(L.dinv, double, n);
-        AMG_TAKE(L.x, double, n);
-        AMG_TAKE(L.xt, double, n);
-        AMG_TAKE(L.b, double, n);
-        AMG_TAKE(L.r, double, n);
+        AMG_TAKE(L.dinvc, cv_t, n);
+        AMG_TAKE(L.x, cv_t, n);
+        AMG_TAKE(L.xt, cv_t, n);
+        AMG_TAKE(L.b, cv_t, n);
+        AMG_TAKE(L.r, cv_t, n);
         if (lev >= 1 && lev <= h.kdepth) {
-            AMG_TAKE(L.kb, double, n);
-            AMG_TAKE(L.c1, double, n);
-            AMG_TAKE(L.v1, double, n);
-            AMG_TAKE(L.v2, double, n);
+            AMG_TAKE(L.kb, cv_t, n);
+            AMG_TAKE(L.c1, cv_t, n);
+            AMG_TAKE(L.v1, cv_t, n);
+            AMG_TAKE(L.v2, cv_t, n);
             void *ks;
             AMG_TAKE(ks, char, sizeof(KScalars));
             L.kscal = ks;
         }
         hipLaunchKernelGGL(k_dinv, dim3(grid_for(n)), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, n, L.dinv);
+        hipLaunchKernelGGL(k_to_cv, dim3(grid_for(n)), dim3(kBlock), 0, st, L.dinv, n, L.dinvc);
         L.agg = nullptr;
         L.memptr = nullptr;
         L.memidx = nullptr;
@@ -1032,30 +1069,30 @@ static dim3 l0_grid(const AmgHierarchy &h)
     return dim3(static_cast<unsigned>((h.l0_cols + per_block - 1) / per_block), static_cast<unsigned>(h.l0_rows));
 }
 
-static void launch_jacobi(AmgHierarchy &h, size_t lev, const double *x, double *xn, hipStream_t st, double w = kOmega)
+static void launch_jacobi(AmgHierarchy &h, size_t lev, const cv_t *x, cv_t *xn, hipStream_t st, double w = kOmega)
 {
     AmgLevel &L = h.levels[lev];
-    if (lev == 0 && h.l0_rinv && !getenv("SSRS_AMG_L0_CSR")) {
-        const L0Stencil a{h.l0_rinv, h.l0_fixed, h.l0_rows, h.l0_cols};
-        hipLaunchKernelGGL(k_l0_jacobi, l0_grid(h), dim3(kBlock), 0, st, a, L.dinv, L.b, x, xn, w);
+    if (lev == 0 && h.l0_rinvc && !getenv("SSRS_AMG_L0_CSR")) {
+        const L0Stencil a{h.l0_rinvc, h.l0_fixed, h.l0_rows, h.l0_cols};
+        hipLaunchKernelGGL(k_l0_jacobi, l0_grid(h), dim3(kBlock), 0, st, a, L.dinvc, L.b, x, xn, static_cast<cv_t>(w));
     } else {
         const dim3 g4(grid_for((static_cast<size_t>(L.n) + kRowsPerGroup - 1) / kRowsPerGroup * kRowLanes)), g1(grid_for(L.n));
         if (L.n >= kVectorRows && L.val32)
-            hipLaunchKernelGGL(k_jacobi4<float>, g4, dim3(kBlock), 0, st, L.rowptr, L.col, L.val32, L.dinv, L.b, x, L.n, xn, w);
+            hipLaunchKernelGGL(k_jacobi4<float>, g4, dim3(kBlock), 0, st, L.rowptr, L.col, L.val32, L.dinvc, L.b, x, L.n, xn, w);
         else if (L.n >= kVectorRows)
-            hipLaunchKernelGGL(k_jacobi4<double>, g4, dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.dinv, L.b, x, L.n, xn, w);
+            hipLaunchKernelGGL(k_jacobi4<double>, g4, dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.dinvc, L.b, x, L.n, xn, w);
         else if (L.val32)
-            hipLaunchKernelGGL(k_jacobi<float>, g1, dim3(kBlock), 0, st, L.rowptr, L.col, L.val32, L.dinv, L.b, x, L.n, xn, w);
+            hipLaunchKernelGGL(k_jacobi<float>, g1, dim3(kBlock), 0, st, L.rowptr, L.col, L.val32, L.dinvc, L.b, x, L.n, xn, w);
         else
-            hipLaunchKernelGGL(k_jacobi<double>, g1, dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.dinv, L.b, x, L.n, xn, w);
+            hipLaunchKernelGGL(k_jacobi<double>, g1, dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.dinvc, L.b, x, L.n, xn, w);
     }
 }
 
 static void launch_residual(AmgHierarchy &h, size_t lev, hipStream_t st)
 {
     AmgLevel &L = h.levels[lev];
-    if (lev == 0 && h.l0_rinv && !getenv("SSRS_AMG_L0_CSR")) {
-        const L0Stencil a{h.l0_rinv, h.l0_fixed, h.l0_rows, h.l0_cols};
+    if (lev == 0 && h.l0_rinvc && !getenv("SSRS_AMG_L0_CSR")) {
+        const L0Stencil a{h.l0_rinvc, h.l0_fixed, h.l0_rows, h.l0_cols};
         hipLaunchKernelGGL(k_l0_residual, l0_grid(h), dim3(kBlock), 0, st, a, L.b, L.x, L.r);
     } else {
         const dim3 g4(grid_for((static_cast<size_t>(L.n) + kRowsPerGroup - 1) / kRowsPerGroup * kRowLanes)), g1(grid_for(L.n));
@@ -1086,18 +1123,30 @@ static void cycle(AmgHierarchy &h, size_t lev, hipStream_t st)
             hipLaunchKernelGGL(k_dense_apply, dim3(gd), dim3(kBlock), 0, st, h.dense_inv, L.r, n, L.xt);
             hipLaunchKernelGGL(k_axpy1, dim3(g), dim3(kBlock), 0, st, L.xt, n, L.x);
         } else {                                   // stalled coarsening: relax
-            hipLaunchKernelGGL(k_jacobi_first, dim3(g), dim3(kBlock), 0, st, L.dinv, L.b, n, L.x, kOmega);
+            hipLaunchKernelGGL(k_jacobi_first, dim3(g), dim3(kBlock), 0, st, L.dinvc, L.b, n, L.x, kOmega);
             for (int s = 0; s < 20; ++s) {
-                hipLaunchKernelGGL(k_jacobi, dim3(g), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.dinv, L.b, L.x, n, L.xt, kOmega);
-                hipLaunchKernelGGL(k_jacobi, dim3(g), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.dinv, L.b, L.xt, n, L.x, kOmega);
+                hipLaunchKernelGGL(k_jacobi, dim3(g), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.dinvc, L.b, L.x, n, L.xt, kOmega);
+                hipLaunchKernelGGL(k_jacobi, dim3(g), dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.dinvc, L.b, L.xt, n, L.x, kOmega);
             }
         }
+        return;
+    }
+    if ((lev == 0 ? h.nu0 : h.nuc) == 1) {
+        // V(1,1): x = w D^-1 b, coarse correction, one sweep with the same step (self-adjoint in the D inner product)
+        hipLaunchKernelGGL(k_jacobi_first, dim3(g), dim3(kBlock), 0, st, L.dinvc, L.b, n, L.x, h.om[0]);
+        launch_residual(h, lev, st);
+        AmgLevel &C1 = h.levels[lev + 1];
+        hipLaunchKernelGGL(k_restrict, dim3(grid_for(C1.n)), dim3(kBlock), 0, st, L.memptr, L.memidx, L.r, C1.n, C1.b);
+        solve_level(h, lev + 1, st);
+        hipLaunchKernelGGL(k_prolong_add, dim3(g), dim3(kBlock), 0, st, L.agg, C1.x, n, L.x);
+        launch_jacobi(h, lev, L.x, L.xt, st, h.om[0]);
+        std::swap(L.x, L.xt);          // the result is in what L.x names from here on (a captured graph keeps the buffers)
         return;
     }
     // pre-smoothing: 2*sweeps Jacobi sweeps from x = 0
     // (step sizes of a pair of sweeps: h.om[0], h.om[1] before the coarse correction, the same in reverse after it --
     // the smoother stays self-adjoint in the D inner product whatever the two are)
-    hipLaunchKernelGGL(k_jacobi_first, dim3(g), dim3(kBlock), 0, st, L.dinv, L.b, n, L.xt, h.om[0]);
+    hipLaunchKernelGGL(k_jacobi_first, dim3(g), dim3(kBlock), 0, st, L.dinvc, L.b, n, L.xt, h.om[0]);
     launch_jacobi(h, lev, L.xt, L.x, st, h.om[1]);
     for (int s = 1; s < h.sweeps; ++s) {
         launch_jacobi(h, lev, L.x, L.xt, st, h.om[0]);
@@ -1183,15 +1232,16 @@ void amg_release(AmgHierarchy &h)
     h.graph_exec = nullptr;
 }
 
-void amg_apply(AmgHierarchy &h, const double *rhs, double *out, hipStream_t st)
+void amg_apply(AmgHierarchy &h, const double *rhs, double *out, const double *norm2, hipStream_t st)
 {
     AmgLevel &L = h.levels[0];
     ensure_graph(h, st);
-    hipLaunchKernelGGL(k_copy, dim3(grid_for(L.n)), dim3(256), 0, st, rhs, L.b, static_cast<size_t>(L.n));
+    if (sizeof(cv_t) == sizeof(double)) norm2 = nullptr;      // the scaling only serves the f32 option's range
+    hipLaunchKernelGGL(k_cycle_in, dim3(grid_for(L.n)), dim3(256), 0, st, rhs, norm2, L.b, static_cast<size_t>(L.n));
     if (h.graph_exec == nullptr ||
         hipGraphLaunch(static_cast<hipGraphExec_t>(h.graph_exec), st) != hipSuccess)
         cycle(h, 0, st);
-    hipLaunchKernelGGL(k_copy, dim3(grid_for(L.n)), dim3(256), 0, st, L.x, out, static_cast<size_t>(L.n));
+    hipLaunchKernelGGL(k_cycle_out, dim3(grid_for(L.n)), dim3(256), 0, st, h.levels[0].x, norm2, out, static_cast<size_t>(L.n));
 }
 
 }  // namespace ssrs

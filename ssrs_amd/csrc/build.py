@@ -60,8 +60,30 @@ def build_probe(defines, tag):
     return out
 
 
+def build_variant(defines, tag, sources=('amg.hip', 'potential.hip'), travel=False):
+    """A/B variant of the product library: `sources` recompiled with -D<defines>, linked with the product's other
+    objects into libssrs_probe_<tag>.so (SSRS_HIP_LIB selects it)."""
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    build()
+    out = os.path.join(PKG, f'libssrs_{"ab" if travel else "probe"}_{tag}.so')      # (probe libraries do not travel to the GPU box)
+    objs = []
+    for s in SOURCES:
+        if s in sources:
+            o = os.path.join(HERE, os.path.splitext(s)[0] + f'_probe_{tag}.o')
+            subprocess.check_call([hipcc] + FLAGS + [f'-D{d}' for d in defines] + ['-c', os.path.join(HERE, s), '-o', o])
+        else:
+            o = os.path.join(HERE, os.path.splitext(s)[0] + '.o')
+        objs.append(o)
+    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs + ['-ldl'])
+    return out
+
+
 if __name__ == '__main__':
-    if '--probe-k3' in sys.argv:      # binning-kernel timing probes (wrong histograms: bench timing only, no checks)
+    if '--win72' in sys.argv:         # 72-row block windows: two k_step_roam blocks per CU (A/B, results identical)
+        print(build_variant(['SSRS_WIN_ROWS=72'], 'win72', sources=('tracks.hip',), travel=True))
+    elif '--amg-f32' in sys.argv:       # the f32 V-cycle measured and rejected in round 4 (stalls at 1e-8: amg.h)
+        print(build_variant(['SSRS_AMG_CYCLE_F32'], 'amg_f32'))
+    elif '--probe-k3' in sys.argv:      # binning-kernel timing probes (wrong histograms: bench timing only, no checks)
         for tag, defs in (('k3_noflush', ['SSRS_PROBE_K3_NOFLUSH']), ('k3_noread', ['SSRS_PROBE_K3_NOREAD'])):
             print(build_probe(defs, tag))
     elif '--probe-k2a' in sys.argv:     # table-builder timing probes: tools/dev/time_k2a.py ONLY (the tables are garbage)

@@ -560,6 +560,10 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
         double a0 = 0.7, a1 = 0.7;
         if (std::sscanf(e, "%lf,%lf", &a0, &a1) == 2 && a0 > 0.0 && a1 > 0.0) { amg.om[0] = a0; amg.om[1] = a1; }
     }
+    if (const char *e = std::getenv("SSRS_AMG_NU")) {
+        int a0 = 2, a1 = 2;
+        if (std::sscanf(e, "%d,%d", &a0, &a1) == 2) { amg.nu0 = a0 == 1 ? 1 : 2; amg.nuc = a1 == 1 ? 1 : 2; }
+    }
     amg.kdepth = (flags & SSRS_SOLVE_K_CYCLE) ? (((flags >> 12) & 15) ? ((flags >> 12) & 15) : 3) : 0;
     amg.symmetric = (flags & SSRS_SOLVE_ONE_SIDED) == 0;
     amg.strong_rounds = ((flags >> 8) & 15) ? ((flags >> 8) & 15) : 4;
@@ -624,7 +628,7 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
             for (int j = 0; j < 5; ++j, ++cg_iterations) {
                 // flexible CG(1): the K-cycle preconditioner is slightly non-linear,
                 // so p is A-orthogonalised explicitly against the previous direction
-                amg_apply(amg, r, phat, st);                                        // z = M r
+                amg_apply(amg, r, phat, &sc->rnorm2, st);                                        // z = M r
                 hipLaunchKernelGGL(k_cg_dot_rz, dim3(nb), dim3(kBlock), 0, st, phat, v, n, sc);      // (z, q_prev)
                 hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, st, sc, FIN_CG_RHO, nb);
                 hipLaunchKernelGGL(k_cg_p, dim3(nb), dim3(kBlock), 0, st, p, phat, n, sc, cg_iterations == 0 ? 1 : 0);
@@ -693,12 +697,12 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
             if (!fresh) hipLaunchKernelGGL(k_update_p, dim3(nb), dim3(kBlock), 0, st, p, r, v, n, sc);
             fresh = false;
             const double *ph = p, *sh = sv;
-            if (use_amg) { amg_apply(amg, p, phat, st); ph = phat; }
+            if (use_amg) { amg_apply(amg, p, phat, &sc->rnorm2, st); ph = phat; }
             if (a.rinv) hipLaunchKernelGGL(k_apply_dot1_wave, dim3(nb), dim3(kBlock), 0, st, a, ph, v, rhat, sc);
             else hipLaunchKernelGGL(k_apply_dot1, dim3(nb), dim3(kBlock), 0, st, a, ph, v, rhat, sc);
             hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, st, sc, FIN_ALPHA, nb);
             hipLaunchKernelGGL(k_form_s, dim3(nb), dim3(kBlock), 0, st, r, v, sv, n, sc);
-            if (use_amg) { amg_apply(amg, sv, shat, st); sh = shat; }
+            if (use_amg) { amg_apply(amg, sv, shat, &sc->rnorm2, st); sh = shat; }
             if (a.rinv) hipLaunchKernelGGL(k_apply_dot2_wave, dim3(nb), dim3(kBlock), 0, st, a, sh, t, sv, sc);
             else hipLaunchKernelGGL(k_apply_dot2, dim3(nb), dim3(kBlock), 0, st, a, sh, t, sv, sc);
             hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, st, sc, FIN_OMEGA, nb);

@@ -684,12 +684,18 @@ struct alignas(16) TrackCtl {
 static_assert(sizeof(TrackCtl) <= 128 * sizeof(uint32_t), "final read-back slot of pinned_counts()");
 
 // block histogram windows of wandering batches (k_step_thr<6>, k_wander_windows)
-constexpr int kWinRows = 144, kWinCols = 256;      // 144 KB of LDS: one block per CU
+// 144 rows: 144 KB of LDS, one block per CU (rounds 2-3); 72 rows: 72 KB, two blocks per CU (-DSSRS_WIN_ROWS=72, A/B)
+#ifndef SSRS_WIN_ROWS
+#define SSRS_WIN_ROWS 144
+#endif
+constexpr int kWinRows = SSRS_WIN_ROWS, kWinCols = 256;
+static_assert(kWinRows == 144 || kWinRows == 72, "a window is 4 or 2 rows of coarse bins");
 constexpr int kWanderWindows = 16;
 constexpr uint32_t kWanderMix = 256;                 // low bits of a sort key: a per-sort hash of the track (k_wander_keys)
-constexpr uint32_t kDealBlocks = 232;              // blocks the contiguous deal spreads the live tracks over (+ one per
-                                                   // window in use and the padding: under the 256 CUs)
-constexpr int kBinRows = kWinRows / 4, kBinCols = kWinCols / 4;
+constexpr uint32_t kDealBlocks = kWinRows == 144 ? 232 : 464;   // blocks the contiguous deal spreads the live tracks over (+ one per
+                                                   // window in use and the padding: under the 256 CUs x blocks per CU)
+constexpr int kBinRows = 36, kBinCols = kWinCols / 4;
+constexpr int kWinBinRows = kWinRows / kBinRows;
 constexpr int kWanderBins = 16384;           // 64 KB of LDS
 struct WanderWindows {
     int32_t n;
@@ -3630,7 +3636,7 @@ __global__ __launch_bounds__(1024) void k_wander_windows(const int32_t *__restri
         for (int q = threadIdx.x; q < nb; q += 1024) {
             const int i = q / nbc, j = q - i * nbc;
             uint32_t sum = 0;
-            for (int di = 0; di < 4 && i + di < nbr; ++di)
+            for (int di = 0; di < kWinBinRows && i + di < nbr; ++di)
                 for (int dj = 0; dj < 4 && j + dj < nbc; ++dj) sum += h[(i + di) * nbc + j + dj];
             const unsigned long long v = (static_cast<unsigned long long>(sum) << 32) | static_cast<uint32_t>(nb - 1 - q);   // ties: lowest bin
             best = v > best ? v : best;
@@ -3648,7 +3654,7 @@ __global__ __launch_bounds__(1024) void k_wander_windows(const int32_t *__restri
         const int q = nb - 1 - static_cast<int>(win & 0xFFFFFFFFull), i = q / nbc, j = q - i * nbc;
         if (threadIdx.x < 16) {
             const int di = threadIdx.x >> 2, dj = threadIdx.x & 3;
-            if (i + di < nbr && j + dj < nbc) h[(i + di) * nbc + j + dj] = 0;
+            if (di < kWinBinRows && i + di < nbr && j + dj < nbc) h[(i + di) * nbc + j + dj] = 0;
         }
         if (threadIdx.x == 0) { out->r0[n] = i * kBinRows; out->c0[n] = j * kBinCols; }
         __syncthreads();
@@ -4436,7 +4442,8 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
             // every list): raise the bound now, and let no batch queued before this point lower it
             // (thinned blocks: at most kDealBlocks + one per window + the padding, 264 blocks = 33 per list)
             unsigned long long padded = static_cast<unsigned long long>(upper) + (kWanderWindows + 1ull) * kBlock;
-            if (deal_contiguous && padded < 34ull * kBlock) padded = 34ull * kBlock;
+            constexpr unsigned long long kDealPerList = (kDealBlocks + kWanderWindows + 1) / kXcd + 3;      // 34 blocks per list (144 rows)
+            if (deal_contiguous && padded < kDealPerList * kBlock) padded = kDealPerList * kBlock;
             upper = padded > ws.cap ? ws.cap : static_cast<uint32_t>(padded);
             upper_from = batches;
         }

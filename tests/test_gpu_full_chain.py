@@ -74,5 +74,29 @@ def test_c1_from_the_dem_with_the_builds_own_fields(gpu, golden):
     same2 = np.mean((out2.lengths.cpu().numpy() == g['lengths']) & (out2.ends.cpu().numpy() == g['ends']).all(1))
     print(f'tracks on K1 orograph + reference potential: identical {same2:.3f}')
     assert same2 >= 0.99          # the <= 1 ulp orograph cells may flip a handful of tracks
-    # about twice what the build shows (mean |d| 2e-4, max |d| 0.047, correlation 0.9985)
-    assert stat[0] <= 5e-4 and stat[1] <= 0.10 and stat[2] >= 0.997, stat
+    # The yardstick is measured here, not assumed (profiles/r04_chain_noise.txt).  Sampling noise is NOT what
+    # limits the agreement: another Philox seed on the reference's field reproduces the golden map to mean |d|
+    # 1e-4, max |d| 0.015, correlation 0.9998.  The potential is: a track is a chaotic function of the f32
+    # field, so the map is only defined up to the field's own uncertainty -- perturbing the REFERENCE's field by
+    # random -1 / 0 / +1 f32 ulp (SuperLU's field is up to 12 ulp from the exact solution, G12) moves its map by
+    # mean |d| 2.4e-4 .. 5.8e-4, max |d| 0.06 .. 0.14, correlation 0.983 .. 0.998.  K5's field (which is closer to the
+    # exact solution than SuperLU's) must move the map no more than the worst of three such perturbations does.
+    # (Rounds 1-3 asserted fixed numbers, about twice what one build showed: 5e-4 / 0.10 / 0.997; the V(1,1)
+    # solver's field gives 2.0e-4 / 0.095 / 0.9952, the V(2,2) one 1.7e-4 / 0.047 / 0.9985: two realisations.)
+    def metrics(potential, seed=30):
+        o = movmodel.simulate_tracks(0., np.stack([r, c], 1), shape, 1, 1., upd, potential, seed=seed, use_table=True)
+        a = torch.zeros(shape, dtype=torch.float64, device='cuda')
+        presence.normalise_add(presence.smooth_presence_counts(o.hist, krad), a)
+        m = presence.normalise_to_f32(a).cpu().numpy()[::8, ::8]
+        d_ = np.abs(m.astype(np.float64) - g['presence_strided'])
+        return d_.mean(), d_.max(), np.corrcoef(m.ravel(), g['presence_strided'].ravel())[0, 1]
+    sampling = metrics(g['potential'], seed=31)
+    print(f'another seed on the reference field: mean |d| {sampling[0]:.4f}, max |d| {sampling[1]:.4f}, corr {sampling[2]:.4f}')
+    rng = np.random.default_rng(0)
+    noise = []
+    for _ in range(3):
+        step = rng.integers(-1, 2, g['potential'].shape).astype(np.int32)
+        noise.append(metrics((g['potential'].view(np.int32) + step).view(np.float32)))
+        print(f'reference field +- 1 ulp: mean |d| {noise[-1][0]:.4f}, max |d| {noise[-1][1]:.4f}, corr {noise[-1][2]:.4f}')
+    noise = (max(n[0] for n in noise), max(n[1] for n in noise), min(n[2] for n in noise))
+    assert stat[0] <= noise[0] and stat[1] <= noise[1] and stat[2] >= noise[2], (stat, noise)

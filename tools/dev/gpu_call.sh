@@ -9,7 +9,7 @@ TAG=${TAG:-r04_call}; TESTS=${TESTS:-all}; SOAK=${SOAK:-0}; BENCH=${BENCH:-none}
 OUT=gpurun_out/$TAG; mkdir -p "$OUT"
 if [ "$TESTS" != none ]; then
     if [ "$TESTS" = all ]; then sel=(tests); elif [[ "$TESTS" == tests/* ]]; then sel=($TESTS); else sel=(tests -k "$TESTS"); fi
-    timeout -k 10 ${TEST_TIMEOUT:-1000} python -m pytest "${sel[@]}" -x -q -m gpu --durations=15 > "$OUT/tests.log" 2>&1
+    timeout -k 10 ${TEST_TIMEOUT:-1000} python -m pytest "${sel[@]}" ${PYTEST_X--x} -q -m gpu --durations=15 > "$OUT/tests.log" 2>&1
     rc=$?; echo "tests rc $rc"; tail -${TEST_TAIL:-8} "$OUT/tests.log"; [ $rc -eq 0 ] || exit 1
 fi
 if [ "$SOAK" != 0 ]; then
