@@ -58,8 +58,9 @@ def parse():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--tracks', type=int, default=100_000, help='tracks per GPU')
-    ap.add_argument('--hist-safe-tracks', type=int, default=200_000,
-                    help='tracks per sub-batch of a pass (a uint32 histogram is safe for this many on the solved field)')
+    ap.add_argument('--hist-safe-tracks', type=int, default=140_000,
+                    help='tracks per sub-batch of a pass (Config.hist_safe_tracks: a uint32 histogram is safe for this many on the '
+                         'solved field, and their ~58 000 roaming survivors are one full block per CU)')
     ap.add_argument('--resolution', type=float, default=10.0)
     ap.add_argument('--width-km', type=float, nargs=2, default=(60.0, 50.0))
     ap.add_argument('--direct', action='store_true', help='3x3 window gathers, no table')

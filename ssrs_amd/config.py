@@ -96,7 +96,11 @@ class Config:
     steps_per_launch: int = 0           # 0 = library default
     max_tracks_file_gb: float = 64.     # refuse a <id>_tracks.pkl larger than this (tracks that wander to
     #                                     max_moves: 1 TB per 100k tracks on a solved 10 m field)
-    hist_safe_tracks: int = 200_000     # tracks per uint32 presence histogram; more are added up in 64 bits
+    hist_safe_tracks: int = 140_000     # tracks per sub-batch of a case: (i) a uint32 presence histogram is safe for this many (more
+    #                                     are added up in 64 bits); (ii) on solved 10 m fields ~42 % of a batch ends up roaming, and
+    #                                     the roaming stepper holds ONE block of 256 tracks per CU: 140 000 tracks leave ~58 000
+    #                                     survivors = one full block on each of the 256 CUs (3.1e11 steps/s); a batch of 200 000
+    #                                     needs a second, 28 % full round of blocks (2.1e11; profiles/r04_roam_fill.txt)
 
     def __str__(self):
         known = {f.name for f in fields(self)}

@@ -39,8 +39,9 @@ struct AmgHierarchy {
     std::vector<AmgLevel> levels;
     double *dense_inv = nullptr;   // inverse of the last level when it is small
     size_t workspace_used = 0;
-    void *graph_exec = nullptr;    // hipGraphExec_t of one captured cycle (NULL: direct launches)
-    bool graph_tried = false;
+    void *graph_exec[2] = {nullptr, nullptr};   // hipGraphExec_t of the captured fast / robust cycle (NULL: direct launches)
+    bool graph_tried[2] = {false, false};
+    bool robust = false;           // the cycle being run / captured: V(2,2) everywhere instead of (nu0, nuc)
     bool symmetric = true;         // symmetric strength of connection (amg.hip: strong_link)
     int strong_rounds = 4;         // matching rounds restricted to strong couplings (of 8)
     int kdepth = 0;                // coarse levels 1..kdepth use the K-cycle (0 = V-cycle)
@@ -62,7 +63,8 @@ int amg_setup(AmgHierarchy &h, const double *cond, const uint8_t *fixed, int row
               void *workspace, size_t workspace_bytes, hipStream_t st);
 // out = M rhs (one V-cycle); rhs/out: f64 vectors on the raster numbering.  `norm2` (device, may be NULL): a value of
 // the order of |rhs|^2 -- the cycle runs on rhs / sqrt(norm2) and the result is scaled back (M is linear)
-void amg_apply(AmgHierarchy &h, const double *rhs, double *out, const double *norm2, hipStream_t st);
+// robust: the V(2,2) cycle of rounds 1-3 whatever nu0 / nuc say (BiCGStab takes it when it stagnates under V(1,1))
+void amg_apply(AmgHierarchy &h, const double *rhs, double *out, const double *norm2, hipStream_t st, bool robust = false);
 // Frees host-side resources (the captured graph); device memory is the caller's.
 void amg_release(AmgHierarchy &h);
 

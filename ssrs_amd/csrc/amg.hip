@@ -1088,22 +1088,23 @@ static void launch_jacobi(AmgHierarchy &h, size_t lev, const cv_t *x, cv_t *xn, 
     }
 }
 
-static void launch_residual(AmgHierarchy &h, size_t lev, hipStream_t st)
+static void launch_residual(AmgHierarchy &h, size_t lev, hipStream_t st, const cv_t *x = nullptr)
 {
     AmgLevel &L = h.levels[lev];
+    if (!x) x = L.x;
     if (lev == 0 && h.l0_rinvc && !getenv("SSRS_AMG_L0_CSR")) {
         const L0Stencil a{h.l0_rinvc, h.l0_fixed, h.l0_rows, h.l0_cols};
-        hipLaunchKernelGGL(k_l0_residual, l0_grid(h), dim3(kBlock), 0, st, a, L.b, L.x, L.r);
+        hipLaunchKernelGGL(k_l0_residual, l0_grid(h), dim3(kBlock), 0, st, a, L.b, x, L.r);
     } else {
         const dim3 g4(grid_for((static_cast<size_t>(L.n) + kRowsPerGroup - 1) / kRowsPerGroup * kRowLanes)), g1(grid_for(L.n));
         if (L.n >= kVectorRows && L.val32)
-            hipLaunchKernelGGL(k_residual4<float>, g4, dim3(kBlock), 0, st, L.rowptr, L.col, L.val32, L.b, L.x, L.n, L.r);
+            hipLaunchKernelGGL(k_residual4<float>, g4, dim3(kBlock), 0, st, L.rowptr, L.col, L.val32, L.b, x, L.n, L.r);
         else if (L.n >= kVectorRows)
-            hipLaunchKernelGGL(k_residual4<double>, g4, dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.b, L.x, L.n, L.r);
+            hipLaunchKernelGGL(k_residual4<double>, g4, dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.b, x, L.n, L.r);
         else if (L.val32)
-            hipLaunchKernelGGL(k_residual<float>, g1, dim3(kBlock), 0, st, L.rowptr, L.col, L.val32, L.b, L.x, L.n, L.r);
+            hipLaunchKernelGGL(k_residual<float>, g1, dim3(kBlock), 0, st, L.rowptr, L.col, L.val32, L.b, x, L.n, L.r);
         else
-            hipLaunchKernelGGL(k_residual<double>, g1, dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.b, L.x, L.n, L.r);
+            hipLaunchKernelGGL(k_residual<double>, g1, dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.b, x, L.n, L.r);
     }
 }
 
@@ -1131,16 +1132,16 @@ static void cycle(AmgHierarchy &h, size_t lev, hipStream_t st)
         }
         return;
     }
-    if ((lev == 0 ? h.nu0 : h.nuc) == 1) {
-        // V(1,1): x = w D^-1 b, coarse correction, one sweep with the same step (self-adjoint in the D inner product)
-        hipLaunchKernelGGL(k_jacobi_first, dim3(g), dim3(kBlock), 0, st, L.dinvc, L.b, n, L.x, h.om[0]);
-        launch_residual(h, lev, st);
+    if (!h.robust && (lev == 0 ? h.nu0 : h.nuc) == 1) {
+        // V(1,1): x = w D^-1 b, coarse correction, one sweep with the same step (self-adjoint in the D inner product);
+        // the iterate lives in L.xt until the last sweep writes L.x
+        hipLaunchKernelGGL(k_jacobi_first, dim3(g), dim3(kBlock), 0, st, L.dinvc, L.b, n, L.xt, h.om[0]);
+        launch_residual(h, lev, st, L.xt);
         AmgLevel &C1 = h.levels[lev + 1];
         hipLaunchKernelGGL(k_restrict, dim3(grid_for(C1.n)), dim3(kBlock), 0, st, L.memptr, L.memidx, L.r, C1.n, C1.b);
         solve_level(h, lev + 1, st);
-        hipLaunchKernelGGL(k_prolong_add, dim3(g), dim3(kBlock), 0, st, L.agg, C1.x, n, L.x);
-        launch_jacobi(h, lev, L.x, L.xt, st, h.om[0]);
-        std::swap(L.x, L.xt);          // the result is in what L.x names from here on (a captured graph keeps the buffers)
+        hipLaunchKernelGGL(k_prolong_add, dim3(g), dim3(kBlock), 0, st, L.agg, C1.x, n, L.xt);
+        launch_jacobi(h, lev, L.xt, L.x, st, h.om[0]);
         return;
     }
     // pre-smoothing: 2*sweeps Jacobi sweeps from x = 0
@@ -1200,8 +1201,9 @@ static void solve_level(AmgHierarchy &h, size_t lev, hipStream_t st)
 // fails, the kernels are launched directly.
 static void ensure_graph(AmgHierarchy &h, hipStream_t st)
 {
-    if (h.graph_tried) return;
-    h.graph_tried = true;
+    const int which = h.robust ? 1 : 0;
+    if (h.graph_tried[which]) return;
+    h.graph_tried[which] = true;
     if (st == nullptr) return;
     hipGraph_t graph = nullptr;
     hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
@@ -1219,7 +1221,7 @@ static void ensure_graph(AmgHierarchy &h, hipStream_t st)
     }
     hipGraphExec_t exec = nullptr;
     e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    if (e == hipSuccess) h.graph_exec = exec;
+    if (e == hipSuccess) h.graph_exec[which] = exec;
     else (void)hipGetLastError();
     if (std::getenv("SSRS_PROGRESS"))
         fprintf(stderr, "[amg] V-cycle graph: %s\n", e == hipSuccess ? "captured" : hipGetErrorString(e));
@@ -1228,18 +1230,21 @@ static void ensure_graph(AmgHierarchy &h, hipStream_t st)
 
 void amg_release(AmgHierarchy &h)
 {
-    if (h.graph_exec) (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(h.graph_exec));
-    h.graph_exec = nullptr;
+    for (int k = 0; k < 2; ++k) {
+        if (h.graph_exec[k]) (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(h.graph_exec[k]));
+        h.graph_exec[k] = nullptr;
+    }
 }
 
-void amg_apply(AmgHierarchy &h, const double *rhs, double *out, const double *norm2, hipStream_t st)
+void amg_apply(AmgHierarchy &h, const double *rhs, double *out, const double *norm2, hipStream_t st, bool robust)
 {
     AmgLevel &L = h.levels[0];
+    h.robust = robust;
     ensure_graph(h, st);
     if (sizeof(cv_t) == sizeof(double)) norm2 = nullptr;      // the scaling only serves the f32 option's range
     hipLaunchKernelGGL(k_cycle_in, dim3(grid_for(L.n)), dim3(256), 0, st, rhs, norm2, L.b, static_cast<size_t>(L.n));
-    if (h.graph_exec == nullptr ||
-        hipGraphLaunch(static_cast<hipGraphExec_t>(h.graph_exec), st) != hipSuccess)
+    void *exec = h.graph_exec[robust ? 1 : 0];
+    if (exec == nullptr || hipGraphLaunch(static_cast<hipGraphExec_t>(exec), st) != hipSuccess)
         cycle(h, 0, st);
     hipLaunchKernelGGL(k_cycle_out, dim3(grid_for(L.n)), dim3(256), 0, st, h.levels[0].x, norm2, out, static_cast<size_t>(L.n));
 }

@@ -692,17 +692,24 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
     // what is left of the iteration budget (at least 50)
     int bicg_cap = max_iterations;
     if (use_amg) bicg_cap = max_iterations - cg_iterations > 50 ? max_iterations - cg_iterations : 50;
+    // BiCGStab can stagnate under the V(1,1) cycle (snapshot 25 of configs[4]: the carried residual sat at 1.7e-11 for
+    // 1 700 iterations, profiles/r04_k5.md) where the V(2,2) cycle of rounds 1-3 converges: a healthy run gains a factor
+    // of ten every ~15 iterations, so 40 iterations without a factor of two switch the preconditioner to the
+    // robust cycle for the rest of the solve (no restart: x and r stay consistent, only the search directions change)
+    bool robust_cycle = false;
+    double gain_mark = 1e300;
+    int gain_it = 0, robust_from = -1;
     while (it < bicg_cap) {
         for (int j = 0; j < check_every && it < bicg_cap; ++j, ++it) {
             if (!fresh) hipLaunchKernelGGL(k_update_p, dim3(nb), dim3(kBlock), 0, st, p, r, v, n, sc);
             fresh = false;
             const double *ph = p, *sh = sv;
-            if (use_amg) { amg_apply(amg, p, phat, &sc->rnorm2, st); ph = phat; }
+            if (use_amg) { amg_apply(amg, p, phat, &sc->rnorm2, st, robust_cycle); ph = phat; }
             if (a.rinv) hipLaunchKernelGGL(k_apply_dot1_wave, dim3(nb), dim3(kBlock), 0, st, a, ph, v, rhat, sc);
             else hipLaunchKernelGGL(k_apply_dot1, dim3(nb), dim3(kBlock), 0, st, a, ph, v, rhat, sc);
             hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, st, sc, FIN_ALPHA, nb);
             hipLaunchKernelGGL(k_form_s, dim3(nb), dim3(kBlock), 0, st, r, v, sv, n, sc);
-            if (use_amg) { amg_apply(amg, sv, shat, &sc->rnorm2, st); sh = shat; }
+            if (use_amg) { amg_apply(amg, sv, shat, &sc->rnorm2, st, robust_cycle); sh = shat; }
             if (a.rinv) hipLaunchKernelGGL(k_apply_dot2_wave, dim3(nb), dim3(kBlock), 0, st, a, sh, t, sv, sc);
             else hipLaunchKernelGGL(k_apply_dot2, dim3(nb), dim3(kBlock), 0, st, a, sh, t, sv, sc);
             hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, st, sc, FIN_OMEGA, nb);
@@ -722,6 +729,12 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
             SSRS_HIP_CHECK(hipMemcpyAsync(xbest, x, n * sizeof(double), hipMemcpyDeviceToDevice, st));
             if (rel <= rel_tol) { converged = 1; break; }
         }
+        if (finite && now < 0.5 * gain_mark) { gain_mark = now; gain_it = it; }
+        else if (use_amg && !robust_cycle && it - gain_it >= 40) {
+            robust_cycle = true;
+            robust_from = it;
+            if (progress) fprintf(stderr, "[ssrs_potential_solve] BiCGStab it %d: no factor of two in 40 iterations (|r|/|b| %.3e): V(2,2) from here on\n", it, now);
+        }
         // BiCGStab breakdown (rho or omega -> 0) or a residual that ran away:
         // restart from the best iterate with a fresh shadow residual
         if (!finite || now > 1e3 * best) {
@@ -739,8 +752,8 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
         hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, st, sc, FIN_INIT, nb);
         SSRS_HIP_CHECK(hipMemcpyAsync(host, &sc->rnorm2, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
         SSRS_HIP_CHECK(hipStreamSynchronize(st));
-        fprintf(stderr, "[ssrs_potential_solve] done: carried |r|/|b| %.3e, recomputed %.3e (PCG %d + BiCGStab %d iterations)\n", rel,
-                host[1] > 0.0 ? std::sqrt(host[0] / host[1]) : 0.0, cg_iterations, it);
+        fprintf(stderr, "[ssrs_potential_solve] done: carried |r|/|b| %.3e, recomputed %.3e (PCG %d + BiCGStab %d iterations%s)\n", rel,
+                host[1] > 0.0 ? std::sqrt(host[0] / host[1]) : 0.0, cg_iterations, it, robust_from >= 0 ? ", the last of them under V(2,2)" : "");
     }
     hipLaunchKernelGGL(k_to_f32, dim3(nb), dim3(kBlock), 0, st, x, potential, n);
     SSRS_HIP_CHECK(hipGetLastError());

@@ -118,3 +118,63 @@ def test_config4_share_batched_rasters_and_concurrent_snapshots(gpu, c2_dem):
         assert np.array_equal(got.lengths.cpu().numpy()[:200], ref['lengths']), s
         assert np.array_equal(got.ends.cpu().numpy()[:200], ref['ends']), s
         assert int(got.hist.sum()) == int(got.lengths.sum())
+
+
+def test_config4_one_gpu_share_through_simulator(gpu, tmp_path):
+    """One GPU's share of BASELINE configs[4] AT ITS SIZE through the product API: seasonal
+    mode, 32 of the 256 synthetic wind snapshots (rank 0's contiguous share on 8 GPUs), 60 x 50 km @10 m, 10 000
+    fluidflow tracks each, default solver tolerance, save_tracks=False
+    (/root/reference/ssrs/simulator.py:200-215 orographs per snapshot, :259-288 one potential per snapshot,
+    :348-369 tracks per snapshot, :518-546 the presence ladder).  Checked: every snapshot's histogram counts every
+    point once; for three snapshots the rasters the run left on disk are stepped again through the library directly
+    (the whole 10 000-track histogram must be bit-equal to the Simulator's) and a 200-track sample by the C oracle on
+    the same rasters (lengths, end cells); the summary map is the ladder of the 32 per-case maps."""
+    import warnings
+    from ssrs_amd import Config, Simulator, movmodel, layers, presence
+    from ssrs_amd.synthetic import wind_lattice
+    from oracle import c_oracle
+    nsnap, ntracks = 32, 10_000
+    wind = []
+    for s in range(nsnap):
+        x, y, ws, wd = wind_lattice((60., 50.), 2.0, phase=2 * np.pi * s / 256)
+        wind.append(dict(datetime=(2010, 1 + s // 28, 1 + s % 28, 12), x_km=x, y_km=y, wspeed=ws, wdirn=wd))
+    cfg = Config(run_name='c5', out_dir=str(tmp_path), max_cores=8, region_width_km=(60., 50.), resolution=RES,
+                 sim_mode='seasonal', track_direction=0., track_count=ntracks, sim_seed=30, save_tracks=False,
+                 print_verbose=False)
+    with warnings.catch_warnings():
+        warnings.filterwarnings('error', message='potential solve stopped')      # a solve that does not converge: fail
+        sim = Simulator(cfg, terrain='synthetic', wind=wind)
+        sim.simulate_tracks()
+    assert len(sim.case_ids) == nsnap and len(sim.last_stats) == nsnap
+    np.random.seed(30)
+    r, c = movmodel.get_starting_indices(ntracks, cfg.track_start_region, cfg.track_start_type, (60., 50.), RES)
+    starts = np.stack([r, c], 1).astype(np.int32)
+    total = 0
+    for case in sim.case_ids:
+        hist = sim._presence_counts[(case, 0)]
+        st = sim.last_stats[(case, 0)]
+        assert int(hist.sum(dtype=torch.int64)) == st['total_steps'] + ntracks, case
+        total += st['total_steps']
+    assert total > 1.0e9
+    for s in (0, 11, 22):
+        case = sim.case_ids[s]
+        oro = torch.from_numpy(np.load(f'{sim._get_orograph_fname(case, sim.mode_data_dir)}.npy')).cuda()
+        pot = torch.from_numpy(np.load(f'{sim._get_potential_fname(case, 0, sim.mode_data_dir)}.npy')).cuda()
+        upd = layers.get_above_threshold_speed(oro, cfg.updraft_threshold)
+        again = movmodel.simulate_tracks(0., starts, SHAPE, 1, 1., upd, pot, seed=30)
+        assert torch.equal(again.hist, sim._presence_counts[(case, 0)]), case
+        ref = c_oracle.simulate_tracks(0., starts[:200], SHAPE, 1, 1., upd.cpu().numpy(), pot.cpu().numpy(), seed=30,
+                                       want_traj=False, want_hist=False)
+        assert np.array_equal(again.lengths.cpu().numpy()[:200], ref['lengths']), case
+        assert np.array_equal(again.ends.cpu().numpy()[:200], ref['ends']), case
+        del oro, pot, upd, again
+    out = sim.compute_presence_map(radius=1000.)
+    krad = presence.presence_kernel_radius(1000., RES, SHAPE)
+    summary = torch.zeros(SHAPE, dtype=torch.float64, device='cuda')
+    for case in sim.case_ids:
+        case_prob = torch.zeros(SHAPE, dtype=torch.float64, device='cuda')
+        presence.normalise_add(presence.smooth_presence_counts(sim._presence_counts[(case, 0)], krad), case_prob)
+        presence.normalise_add(case_prob, summary)
+    assert np.array_equal(out, presence.normalise_to_f32(summary).cpu().numpy())
+    assert out.dtype == np.float32 and float(out.max()) == 1.0 and np.array_equal(
+        out, np.load(tmp_path / 'c5' / 'data' / 'seasonal' / 'summary_presence.npy'))
