@@ -284,7 +284,10 @@ class Passes:
         table = None if args.direct else build_table(args, self.movmodel, upd, self.pot)
         ev[2].record()
         n = int(self.starts.shape[0])
-        safe = max(int(args.hist_safe_tracks), 1)
+        # equal sub-batches of at most --hist-safe-tracks tracks (a last short one would take a full pass's time --
+        # a pass lasts as long as its longest track chain -- for a fraction of the work)
+        nsub = max(1, -(-n // max(int(args.hist_safe_tracks), 1)))
+        safe = max(1, -(-n // nsub))
         outs = []
         hist64 = None
         # more tracks than a uint32 histogram is safe for (trap cells of the solved field collect ~1e4 visits per
@@ -323,6 +326,21 @@ class Passes:
                       'roam_launches', 'roam_wave_pairs', 'roam_slow_wave_pairs', 'roam_fine_settled'):
                 acc[k] += st.get(k, 0)
         return out
+
+    def k1_kernel_seconds(self, launches=20):
+        """K1's own duration: `launches` back-to-back launches between two events on a busy stream (the per-pass
+        figure `raster_ms` brackets ONE launch that follows a host-synchronised stepper call: launch latency and
+        the clocks' ramp after the idle gap are in it, 0.15 against 0.126 ms)."""
+        import torch
+        for _ in range(3):
+            self.k1()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(launches):
+            self.k1()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / 1e3 / launches
 
     def drain(self):
         for i, w in enumerate(self.pending):
@@ -540,7 +558,7 @@ def main():
     hsum = int(hist.sum().item()) if hist.dtype == torch.int64 else int((hist.view(torch.int32).to(torch.int64) & 0xFFFFFFFF).sum().item())
     assert hsum == total_steps_all // K + n_total, 'histogram checksum failed'
     roof, kernel_s = stepper_roofline(args, acc, K, solved)
-    raster_s = acc['raster_ms'] / 1e3 / K
+    raster_s = main_leg.k1_kernel_seconds()
     out = {
         'metric': 'simulated tracks/sec (whole node)',
         'value': n_total * K / elapsed,
@@ -584,6 +602,8 @@ def main():
                          'single-move sequence (near-ties, flag entries); near-ties the 32-bit fine table settled'},
         'raster_mcells_per_s': ncells / raster_s / 1e6 if raster_s > 0 else None,
         'raster_gbps': ncells * RASTER_BYTES_PER_CELL / raster_s / 1e9 if raster_s > 0 else None,
+        'raster_timing': 'K1 kernel duration: 20 back-to-back launches between two HIP events (phase_ms_per_step.raster_k1 is the '
+                         'one launch inside a pass, host launch latency included)',
         'phase_ms_per_step': {
             'raster_k1': acc['raster_ms'] / K, 'table_k2a': acc['table_ms'] / K,
             'stepper_kernels_k2b': acc['step_kernel_ms'] / K,
@@ -613,6 +633,7 @@ def main():
             'value': n_total * k2 / el2, 'unit': 'tracks/s', 'ms_per_step': el2 / k2 * 1e3,
             'steps_per_s': leg.acc['steps'] / el2, 'steps_per_track_mean': float(l2.mean()),
             'steps_per_track_max': int(l2.max()),
+            'raster_mcells_per_s': ncells / leg.k1_kernel_seconds() / 1e6,
             'phase_ms_per_step': {'raster_k1': leg.acc['raster_ms'] / k2, 'table_k2a': leg.acc['table_ms'] / k2,
                                   'stepper_kernels_k2b': leg.acc['step_kernel_ms'] / k2,
                                   'histogram_binning_k3': leg.acc['hist_ms'] / k2},

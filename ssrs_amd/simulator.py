@@ -564,9 +564,12 @@ class Simulator(Config):
         checksum -- the counts must add up to the points of its tracks; a wrapped cell leaves 2^32 missing."""
         from .distributed import HistogramOverflow
         n = int(my_starts.shape[0])
-        step = max(1, int(self.hist_safe_tracks))
+        safe = max(1, int(self.hist_safe_tracks))
+        widen = max(n, int(widest_share or 0)) > safe
+        # equal sub-batches of at most hist_safe_tracks tracks: a pass lasts as long as its longest track chain, so a
+        # short last sub-batch would cost a full pass's time for a fraction of the work
+        step = max(1, -(-n // max(1, -(-n // safe))))
         parts, wide, stats = [], None, None
-        widen = max(n, int(widest_share or 0)) > step
         for t0 in range(0, max(n, 1), step):
             sub = my_starts[t0:t0 + step]
             b = movmodel.simulate_tracks(
