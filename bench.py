@@ -49,7 +49,16 @@ RASTER_BYTES_PER_CELL = 20      # fused K1 as benchmarked: f64 DEM in (8) + f32 
 # second round of blocks).  A pass takes the time of its longest track chain whatever the number of tracks, so this
 # is what the same 1.35 s could carry, not something a 100k-track pass can reach.
 THROUGHPUT_BOUND_STEPS_PER_S = 2.0e11
-ROAM_THROUGHPUT_BOUND_STEPS_PER_S = 2.84e11
+ROAM_THROUGHPUT_BOUND_STEPS_PER_S = 3.1e11       # profiles/r04_roam_fill.txt: 140 000 tracks per call, this round's boxes (2.84e11 in round 3)
+# Independent yardsticks of k_step_roam (not the builder's own kernel at another batch size):
+#  * VALU issue: a wave64 instruction holds its SIMD16 for 4 clocks, so 256 CUs x 4 SIMDs issue 2.4e9 / 4 x 1024 wave-instructions
+#    per second; the kernel spends 118.6 of them per wave-pair (SQ_INSTS_VALU per launch / wave-pairs per launch,
+#    profiles/r04_solved_counters.md), and a wave-pair is 2 x (live lanes of the wave) steps -- live lanes from this run's stats
+#  * the CU's gather path: a fully divergent dwordx4 gather that hits L2 is served at 0.448 lane-loads per clock and CU however
+#    many waves ask (tools/microbench/gather_latency.hip, profiles/r04_gather_latency.txt); one gather per lane and pair of steps
+GPU_CLOCK_HZ, GPU_CUS = 2.4e9, 256
+ROAM_VALU_PER_WAVE_PAIR = 118.6
+GATHER_LANES_PER_CLK_PER_CU = 0.448
 
 
 def parse():
@@ -401,6 +410,18 @@ def stepper_roofline(args, acc, K, solved):
         name = ('k_step_tracks' if (args.direct or args.f64_table or args.exact_only)
                 else ('k_step_lean<ring>' if args.ring_table else 'k_step_thr<4, true, false>')) + ' (K2 stepper, rank 0)'
     sec = ms / 1e3
+    extra = {}
+    if 'k_step_roam' in name and acc.get('roam_wave_pairs', 0) > 0 and steps > 0 and sec > 0:
+        lanes = steps / 2.0 / acc['roam_wave_pairs']                  # live lanes of an average wave
+        issue = GPU_CLOCK_HZ / 4.0 * 4 * GPU_CUS / ROAM_VALU_PER_WAVE_PAIR * lanes * 2.0
+        gather = GATHER_LANES_PER_CLK_PER_CU * GPU_CUS * GPU_CLOCK_HZ * 2.0
+        extra = {'live_lanes_per_wave': lanes,
+                 'valu_issue_bound_steps_per_s': issue, 'valu_issue_frac': steps / sec / issue,
+                 'valu_issue_bound_at_64_lanes_steps_per_s': issue / lanes * 64.0,
+                 'gather_path_bound_steps_per_s': gather, 'gather_path_frac': steps / sec / gather,
+                 'bounds_source': 'VALU: 118.6 wave-VALU per wave-pair (profiles/r04_solved_counters.md) at 1 wave-instruction per 4 '
+                                  'clocks and SIMD; gather path: 0.448 lane-loads per clock and CU (profiles/r04_gather_latency.txt); '
+                                  'live lanes from this run'}
     gbps = steps * bytes_per_step / sec / 1e9 if sec > 0 else 0.0
     model = steps * STEP_BYTES / sec / 1e9 if sec > 0 else 0.0
     sps = steps / sec if sec > 0 else 0.0
@@ -427,6 +448,7 @@ def stepper_roofline(args, acc, K, solved):
         # reads + 1 point); the shipped path precomputes the windows into a table, so this
         # figure can exceed the peak and is not a roofline fraction
         'model_bytes_per_step': STEP_BYTES, 'model_gbps': model, 'model_frac': model / HBM_PEAK_GBPS,
+        **extra,
     }, kernel_s
 
 
