@@ -267,8 +267,9 @@ int ssrs_transition_ring_build(const double *updraft, const float *potential, fl
  * ssrs_transition_thr_bytes(rows, cols) bytes in all, 64-byte aligned; the table belongs to one
  * heading (`prior` [host], 9 doubles = SsrsTrackParams.prior).  rows * cols <= 2^26; the
  * table carries a guard band of (cols + 2) dwords at either end, and the first bytes of the leading band
- * name the table (magic, rows, cols, the nine prior values): ssrs_tracks_simulate checks them on the device
- * and returns SSRS_ERR_INVALID for a buffer that is not the threshold table of its raster and prior. */
+ * name the table (magic, rows, cols, the nine prior values): ssrs_tracks_simulate reads them back and returns
+ * SSRS_ERR_INVALID, before any stepper kernel is launched, for a buffer that is not the threshold table of its
+ * raster and prior (88 bytes and one stream wait per call). */
 size_t ssrs_transition_thr_bytes(int rows, int cols);
 int ssrs_transition_thr_build(const double *updraft, const float *potential, const double *prior,
                               float *thr, int rows, int cols, void *stream);
