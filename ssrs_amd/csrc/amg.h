@@ -45,6 +45,9 @@ struct AmgHierarchy {
     bool symmetric = true;         // symmetric strength of connection (amg.hip: strong_link)
     int strong_rounds = 4;         // matching rounds restricted to strong couplings (of 8)
     int kdepth = 0;                // coarse levels 1..kdepth use the K-cycle (0 = V-cycle)
+    int klevel = 0, kinner = 0;    // ONE level solved by `kinner` flexible-CG steps preconditioned by the cycle below it
+                                   // (0: off; SSRS_AMG_K=level,inner).  Unlike kdepth's nesting (2^depth visits of the deep
+                                   // levels) the levels below are visited kinner times
     int sweeps = 1;                // pairs of Jacobi sweeps before and after the coarse correction
     int nu0 = 1, nuc = 1;          // Jacobi sweeps before / after the coarse correction on level 0 / on the coarser levels:
                                    // 1 (default since round 4: V(1,1), 430 iterations x 5.2 ms at C2) or 2 (rounds 1-3: V(2,2),

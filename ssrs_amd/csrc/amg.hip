@@ -808,6 +808,60 @@ __global__ __launch_bounds__(kBlock) void k_kfinish(KScalars *s, int stage, int 
     }
 }
 
+// ---- single-level K-cycle: flexible CG(1) on one coarse level, scalars on the device
+// stage 1: beta = -(z, q_prev) / (p_prev, q_prev);  stage 2: pq = (p, q), alpha = (p, r) / pq
+__global__ __launch_bounds__(kBlock) void k_k1finish(KScalars *s, int stage, int nblocks, int linear)
+{
+    __shared__ double lds[kBlock / 64];
+    double t[2];
+    for (int k = 0; k < 2; ++k) {
+        double d = 0.0;
+        for (int i = threadIdx.x; i < nblocks; i += kBlock) d += s->part[k][i];
+        t[k] = kblock_sum(d, lds);
+    }
+    if (threadIdx.x != 0) return;
+    if (stage == 1) s->beta = (s->rho1 != 0.0 && !linear) ? -t[0] / s->rho1 : 0.0;          // rho1 holds (p_prev, q_prev)
+    else { s->rho1 = t[0]; s->alpha1 = linear ? 1.0 : (t[0] != 0.0 ? t[1] / t[0] : 0.0); }
+}
+// p = z + beta p (first: p = z)
+__global__ __launch_bounds__(kBlock) void k_k1p(const cv_t *__restrict__ z, int n, const KScalars *s, int first,
+                                               cv_t *__restrict__ p)
+{
+    const double beta = first ? 0.0 : s->beta;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+        p[i] = static_cast<cv_t>(z[i] + beta * (first ? 0.0 : static_cast<double>(p[i])));
+}
+// x += alpha p (first: x = alpha p);  r -= alpha q
+__global__ __launch_bounds__(kBlock) void k_k1xr(const cv_t *__restrict__ p, const cv_t *__restrict__ q, int n,
+                                                const KScalars *s, int first, cv_t *__restrict__ x, cv_t *__restrict__ r)
+{
+    const double alpha = s->alpha1;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        x[i] = static_cast<cv_t>((first ? 0.0 : static_cast<double>(x[i])) + alpha * p[i]);
+        r[i] = static_cast<cv_t>(r[i] - alpha * q[i]);
+    }
+}
+// q = A p with four lanes per row (the CSR sweeps' walk)
+template <class V>
+__global__ __launch_bounds__(kBlock) void k_spmv4(const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                 const V *__restrict__ val, const cv_t *__restrict__ x, int n,
+                                                 cv_t *__restrict__ y)
+{
+    const int sub = threadIdx.x % kRowLanes;
+    const long long groups = static_cast<long long>(gridDim.x) * (kBlock / kRowLanes);
+    for (long long i = blockIdx.x * static_cast<long long>(kBlock / kRowLanes) + threadIdx.x / kRowLanes; i < n;
+         i += groups * kRowsPerGroup) {
+        long long row[kRowsPerGroup];
+        double ax[kRowsPerGroup];
+#pragma unroll
+        for (int u = 0; u < kRowsPerGroup; ++u) row[u] = i + u * groups;
+        rows_dot4(rowptr, col, val, x, row, n, sub, ax);
+#pragma unroll
+        for (int u = 0; u < kRowsPerGroup; ++u)
+            if (sub == 0 && row[u] < n) y[row[u]] = static_cast<cv_t>(ax[u]);
+    }
+}
+
 // r1 = b - f1 v1
 __global__ __launch_bounds__(kBlock) void k_kresid(const cv_t *__restrict__ b,
                                                   const cv_t *__restrict__ v1, int n,
@@ -921,7 +975,7 @@ int amg_setup(AmgHierarchy &h, const double *cond, const uint8_t *fixed, int row
         AMG_TAKE(L.xt, cv_t, n);
         AMG_TAKE(L.b, cv_t, n);
         AMG_TAKE(L.r, cv_t, n);
-        if (lev >= 1 && lev <= h.kdepth) {
+        if ((lev >= 1 && lev <= h.kdepth) || (lev >= 1 && lev == h.klevel && h.kinner > 0)) {
             AMG_TAKE(L.kb, cv_t, n);
             AMG_TAKE(L.c1, cv_t, n);
             AMG_TAKE(L.v1, cv_t, n);
@@ -1171,7 +1225,35 @@ static void cycle(AmgHierarchy &h, size_t lev, hipStream_t st)
 static void solve_level(AmgHierarchy &h, size_t lev, hipStream_t st)
 {
     AmgLevel &L = h.levels[lev];
-    if (lev + 1 == h.levels.size() || static_cast<int>(lev) > h.kdepth || !L.kscal) {
+    if (lev + 1 != h.levels.size() && static_cast<int>(lev) == h.klevel && h.kinner > 0 && L.kscal && !h.robust) {
+        // single-level K-cycle: kinner steps of flexible CG(1) on this level's system, each preconditioned by the
+        // cycle from here down.  r = L.kb, x = L.c1, p = L.v1, q = L.v2, z = L.x
+        const int n = L.n, g = grid_for(n);
+        const int gb = g > 256 ? 256 : g;
+        const dim3 g4(grid_for((static_cast<size_t>(n) + kRowsPerGroup - 1) / kRowsPerGroup * kRowLanes));
+        KScalars *ks = static_cast<KScalars *>(L.kscal);
+        const int klin = std::getenv("SSRS_AMG_K_LINEAR") != nullptr ? 1 : 0;     // experiment: plain repeated cycles (alpha 1, beta 0)
+        hipLaunchKernelGGL(k_copy, dim3(g), dim3(256), 0, st, L.b, L.kb, static_cast<size_t>(n));
+        for (int k = 0; k < h.kinner; ++k) {
+            if (k > 0) hipLaunchKernelGGL(k_copy, dim3(g), dim3(256), 0, st, L.kb, L.b, static_cast<size_t>(n));
+            cycle(h, lev, st);                                                             // z = B r (in L.x)
+            if (k > 0) {
+                hipLaunchKernelGGL(k_dots, dim3(gb), dim3(kBlock), 0, st, L.x, L.v2, nullptr, nullptr, nullptr, nullptr, n, ks);
+                hipLaunchKernelGGL(k_k1finish, dim3(1), dim3(kBlock), 0, st, ks, 1, gb, klin);
+            }
+            hipLaunchKernelGGL(k_k1p, dim3(g), dim3(kBlock), 0, st, L.x, n, ks, k == 0 ? 1 : 0, L.v1);
+            // q = A p from the f64 entries: the f32 copies the sweeps read round the diagonal up and the off-diagonals toward
+            // zero, which multiplies the energy (p, A p) of a floating cluster's level -- a row sum of 1e-8 of the diagonal --
+            // by ~100; the step sizes would come out 100 times too small (measured: alpha 0.01, 1 555 outer iterations)
+            hipLaunchKernelGGL(k_spmv4<double>, g4, dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.v1, n, L.v2);
+            hipLaunchKernelGGL(k_dots, dim3(gb), dim3(kBlock), 0, st, L.v1, L.v2, L.v1, L.kb, nullptr, nullptr, n, ks);
+            hipLaunchKernelGGL(k_k1finish, dim3(1), dim3(kBlock), 0, st, ks, 2, gb, klin);
+            hipLaunchKernelGGL(k_k1xr, dim3(g), dim3(kBlock), 0, st, L.v1, L.v2, n, ks, k == 0 ? 1 : 0, L.c1, L.kb);
+        }
+        hipLaunchKernelGGL(k_copy, dim3(g), dim3(256), 0, st, L.c1, L.x, static_cast<size_t>(n));
+        return;
+    }
+    if (lev + 1 == h.levels.size() || static_cast<int>(lev) > h.kdepth || !L.kscal || (h.klevel > 0 && h.kinner > 0)) {
         cycle(h, lev, st);
         return;
     }

@@ -564,6 +564,10 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
         int a0 = 2, a1 = 2;
         if (std::sscanf(e, "%d,%d", &a0, &a1) == 2) { amg.nu0 = a0 == 1 ? 1 : 2; amg.nuc = a1 == 1 ? 1 : 2; }
     }
+    if (const char *e = std::getenv("SSRS_AMG_K")) {
+        int a0 = 0, a1 = 0;
+        if (std::sscanf(e, "%d,%d", &a0, &a1) == 2 && a0 >= 1 && a0 <= 40 && a1 >= 1 && a1 <= 16) { amg.klevel = a0; amg.kinner = a1; }
+    }
     amg.kdepth = (flags & SSRS_SOLVE_K_CYCLE) ? (((flags >> 12) & 15) ? ((flags >> 12) & 15) : 3) : 0;
     amg.symmetric = (flags & SSRS_SOLVE_ONE_SIDED) == 0;
     amg.strong_rounds = ((flags >> 8) & 15) ? ((flags >> 8) & 15) : 4;

@@ -8,7 +8,7 @@ from ssrs_amd.potential import solve_potential
 from ssrs_amd.synthetic import synthetic_dem
 
 shape = tuple(int(v) for v in sys.argv[1].split('x')) if len(sys.argv) > 1 else (5000, 6000)
-only = sys.argv[2].split(',') if len(sys.argv) > 2 else None
+only = sys.argv[2].split(';') if len(sys.argv) > 2 else None
 dem = torch.from_numpy(synthetic_dem(shape, 10.)).cuda()
 _, upd = layers.updraft_from_dem(dem, 10., 10., 270., threshold=0.75)
 del dem
@@ -21,6 +21,9 @@ variants = [
     ('ramp guess', {}, {'initial_guess': ramp}),
     ('nu 1,1 + ramp', {'SSRS_AMG_NU': '1,1'}, {'initial_guess': ramp}),
 ]
+# single-level K-cycle: SSRS_AMG_K=level,inner
+for lev, inner in ((1, 1), (4, 1), (4, 2), (2, 2), (3, 2), (3, 4), (4, 2), (4, 4), (5, 4), (4, 8), (5, 8), (6, 8)):
+    variants.append((f'K {lev},{inner}', {'SSRS_AMG_K': f'{lev},{inner}'}, {}))
 ref = None
 for label, env, kw in variants:
     if only and label not in only:
