@@ -56,6 +56,11 @@ struct AmgHierarchy {
     // level 0 applied matrix-free (amg.hip: L0Stencil)
     const double *l0_rinv = nullptr;   // +-1 / cond in f64: the outer operator (potential.hip) reads it
     const cv_t *l0_rinvc = nullptr;    // the same in the cycle's precision
+    // level 0 of the V(1,1) cycle fused into two stencil passes that read the caller's right-hand side and write the
+    // caller's result directly (amg.hip: k_l0_pre_fused / k_l0_post_fused); the two pointers travel through a device slot
+    // so that the captured graph serves every (rhs, out) pair.  A/B: SSRS_AMG_NO_FUSE
+    void *l0_slots = nullptr;
+    bool fuse0 = false;
     const uint8_t *l0_fixed = nullptr;
     int l0_rows = 0, l0_cols = 0;
 };

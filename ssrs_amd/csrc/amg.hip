@@ -577,6 +577,94 @@ __device__ __forceinline__ cv_t l0_apply_wave(const L0Stencil &a, const cv_t *__
     return diag * xv[1] - off;
 }
 
+// ---- level 0 of the V(1,1) cycle in two passes (f64 cycle only).  Unfused it is: copy rhs -> b (2 array passes), x = w D^-1 b
+// (3), r = b - A x (4), [restrict], x += P x_c (2.5), x = x + w D^-1 (b - A x) (5), copy x -> out (2) = 18.5 passes of 240 MB
+// at 5000 x 6000; fused: pre (b, dinv, rinv -> x, r: 5) and post (x, agg, x_c, rinv, b, dinv -> out: 6.5) = 11.5.
+struct L0Slots { const double *rhs; double *out; };
+__global__ void k_set_slots(L0Slots *s, const double *rhs, double *out) { s->rhs = rhs; s->out = out; }
+
+// the stencil of l0_apply_wave on values the caller has in registers: xv / sv = this lane's column of rows r-1, r, r+1
+__device__ __forceinline__ double l0_core(const double (&xv)[3], const double (&sv)[3])
+{
+    const double inf = __builtin_inf();
+    const double si = sv[1], ri = fabs(si);
+    double diag = 0.0, off = 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        if (k == 4) continue;
+        const int d = k / 3, dc = k % 3 - 1;
+        double sj = sv[d], xj = xv[d];
+        if (dc < 0) { sj = __shfl_up(sj, 1); xj = __shfl_up(xj, 1); }
+        if (dc > 0) { sj = __shfl_down(sj, 1); xj = __shfl_down(xj, 1); }
+        const double rj = fabs(sj);
+        double w = (ri != 0.0 && rj != 0.0) ? 2.0 / (ri + rj) : 1e-08;
+        if (rj == inf) w = 0.0;
+        if (d != 1 && dc != 0) w = w * kInvFacDiag;
+        diag += w;
+        if (!signbit(sj)) off += w * xj;
+    }
+    if (signbit(si)) return xv[1];                            // Dirichlet cell: identity row
+    return diag * xv[1] - off;
+}
+
+// pre: x = w D^-1 b and r = b - A x in one pass (the neighbours' x is recomputed from their b and dinv)
+__global__ __launch_bounds__(kBlock) void k_l0_pre_fused(const double *__restrict__ rinv, int rows, int cols,
+                                                        const double *__restrict__ dinv, const L0Slots *__restrict__ slots,
+                                                        double w, double *__restrict__ x, double *__restrict__ r)
+{
+    const double *__restrict__ b = slots->rhs;
+    const int c = (static_cast<int>(blockIdx.x) * (kBlock / 64) + static_cast<int>(threadIdx.x >> 6)) * kL0Cols +
+                  static_cast<int>(threadIdx.x & 63) - 1;
+    const int row = static_cast<int>(blockIdx.y), lane = threadIdx.x & 63;
+    const bool col_ok = c >= 0 && c < cols;
+    double xv[3], sv[3], bc = 0.0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int rr = row + d - 1;
+        const bool ok = col_ok && rr >= 0 && rr < rows;
+        const size_t j = static_cast<size_t>(ok ? rr : row) * cols + (col_ok ? c : 0);
+        const double bj = ok ? b[j] : 0.0;
+        xv[d] = ok ? w * dinv[j] * bj : 0.0;
+        sv[d] = ok ? rinv[j] : __builtin_inf();
+        if (d == 1) bc = bj;
+    }
+    const double ax = l0_core(xv, sv);
+    if (col_ok && lane >= 1 && lane <= kL0Cols) {
+        const size_t i = static_cast<size_t>(row) * cols + c;
+        x[i] = xv[1];
+        r[i] = bc - ax;
+    }
+}
+
+// post: x' = x + P x_c (recomputed for the neighbours) and out = x' + w D^-1 (b - A x') in one pass
+__global__ __launch_bounds__(kBlock) void k_l0_post_fused(const double *__restrict__ rinv, int rows, int cols,
+                                                         const double *__restrict__ dinv, const L0Slots *__restrict__ slots,
+                                                         const int *__restrict__ agg, const double *__restrict__ xc,
+                                                         const double *__restrict__ x, double w)
+{
+    const double *__restrict__ b = slots->rhs;
+    double *__restrict__ out = slots->out;
+    const int c = (static_cast<int>(blockIdx.x) * (kBlock / 64) + static_cast<int>(threadIdx.x >> 6)) * kL0Cols +
+                  static_cast<int>(threadIdx.x & 63) - 1;
+    const int row = static_cast<int>(blockIdx.y), lane = threadIdx.x & 63;
+    const bool col_ok = c >= 0 && c < cols;
+    double xv[3], sv[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int rr = row + d - 1;
+        const bool ok = col_ok && rr >= 0 && rr < rows;
+        const size_t j = static_cast<size_t>(ok ? rr : row) * cols + (col_ok ? c : 0);
+        const int a = ok ? agg[j] : -1;
+        xv[d] = ok ? x[j] + (a >= 0 ? xc[a] : 0.0) : 0.0;
+        sv[d] = ok ? rinv[j] : __builtin_inf();
+    }
+    const double ax = l0_core(xv, sv);
+    if (col_ok && lane >= 1 && lane <= kL0Cols) {
+        const size_t i = static_cast<size_t>(row) * cols + c;
+        out[i] = xv[1] + w * dinv[i] * (b[i] - ax);
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_l0_jacobi(L0Stencil a, const cv_t *__restrict__ dinv,
                                                      const cv_t *__restrict__ b,
                                                      const cv_t *__restrict__ x,
@@ -941,6 +1029,9 @@ int amg_setup(AmgHierarchy &h, const double *cond, const uint8_t *fixed, int row
         AMG_TAKE(rinvc, cv_t, n0);
         hipLaunchKernelGGL(k_to_cv, dim3(grid_for(n0)), dim3(kBlock), 0, st, rinv, n0, rinvc);
         h.l0_rinvc = rinvc;
+        void *slots;
+        AMG_TAKE(slots, char, 256);
+        h.l0_slots = slots;
         h.l0_fixed = fixed;
         h.l0_rows = rows;
         h.l0_cols = cols;
@@ -1186,6 +1277,22 @@ static void cycle(AmgHierarchy &h, size_t lev, hipStream_t st)
         }
         return;
     }
+    if (!h.robust && lev == 0 && h.fuse0) {
+        if constexpr (sizeof(cv_t) == sizeof(double)) {
+            const double *rinv = reinterpret_cast<const double *>(h.l0_rinvc);
+            const L0Slots *slots = static_cast<const L0Slots *>(h.l0_slots);
+            AmgLevel &C1 = h.levels[1];
+            hipLaunchKernelGGL(k_l0_pre_fused, l0_grid(h), dim3(kBlock), 0, st, rinv, h.l0_rows, h.l0_cols,
+                               reinterpret_cast<const double *>(L.dinvc), slots, h.om[0], reinterpret_cast<double *>(L.xt),
+                               reinterpret_cast<double *>(L.r));
+            hipLaunchKernelGGL(k_restrict, dim3(grid_for(C1.n)), dim3(kBlock), 0, st, L.memptr, L.memidx, L.r, C1.n, C1.b);
+            solve_level(h, 1, st);
+            hipLaunchKernelGGL(k_l0_post_fused, l0_grid(h), dim3(kBlock), 0, st, rinv, h.l0_rows, h.l0_cols,
+                               reinterpret_cast<const double *>(L.dinvc), slots, L.agg, reinterpret_cast<const double *>(C1.x),
+                               reinterpret_cast<const double *>(L.xt), h.om[0]);
+        }
+        return;
+    }
     if (!h.robust && (lev == 0 ? h.nu0 : h.nuc) == 1) {
         // V(1,1): x = w D^-1 b, coarse correction, one sweep with the same step (self-adjoint in the D inner product);
         // the iterate lives in L.xt until the last sweep writes L.x
@@ -1322,7 +1429,16 @@ void amg_apply(AmgHierarchy &h, const double *rhs, double *out, const double *no
 {
     AmgLevel &L = h.levels[0];
     h.robust = robust;
+    h.fuse0 = sizeof(cv_t) == sizeof(double) && h.l0_rinvc && h.l0_slots && h.nu0 == 1 && h.levels.size() > 1 && h.levels[0].agg &&
+              !std::getenv("SSRS_AMG_L0_CSR") && !std::getenv("SSRS_AMG_NO_FUSE");
     ensure_graph(h, st);
+    if (!robust && h.fuse0) {
+        // the fused level 0 reads `rhs` and writes `out` itself: no staging copies
+        hipLaunchKernelGGL(k_set_slots, dim3(1), dim3(1), 0, st, static_cast<L0Slots *>(h.l0_slots), rhs, out);
+        void *fexec = h.graph_exec[0];
+        if (fexec == nullptr || hipGraphLaunch(static_cast<hipGraphExec_t>(fexec), st) != hipSuccess) cycle(h, 0, st);
+        return;
+    }
     if (sizeof(cv_t) == sizeof(double)) norm2 = nullptr;      // the scaling only serves the f32 option's range
     hipLaunchKernelGGL(k_cycle_in, dim3(grid_for(L.n)), dim3(256), 0, st, rhs, norm2, L.b, static_cast<size_t>(L.n));
     void *exec = h.graph_exec[robust ? 1 : 0];

@@ -162,3 +162,28 @@ def test_potential_workspace_tight_first_try_and_exhaustion(gpu, golden):
     rc = nat.lib().ssrs_potential_solve(nat.ptr(cond), nat.ptr(mask), nat.ptr(vals), None, nat.ptr(out), 500, 600,
                                         C.c_double(1e-10), 100, 0, nat.ptr(ws), C.c_size_t(small), None, stream_ptr())
     assert rc == nat.SSRS_ERR_INVALID and b'workspace' in nat.lib().ssrs_last_error()
+
+
+def test_potential_cycle_switches_agree(gpu):
+    """The solver's A/B switches on one small two-phase raster: the fused level 0 of the V(1,1) cycle is bit-identical to the
+    unfused kernels (SSRS_AMG_NO_FUSE), and the V(2,2) cycle of rounds 1-3 (SSRS_AMG_NU=2,2) converges to the same field
+    within the solver's own uncertainty."""
+    import os
+    from ssrs_amd.potential import solve_potential
+    rng = np.random.default_rng(5)
+    cond = np.abs(rng.normal(0.8, 0.6, (300, 420)))
+    cond[rng.random(cond.shape) < 0.45] = 0.0
+    cond[100:160, 50:300] = 0.0
+    base, st = solve_potential(cond, 0., return_stats=True)
+    assert st['converged']
+    for env, val, exact in (('SSRS_AMG_NO_FUSE', '1', True), ('SSRS_AMG_NU', '2,2', False)):
+        os.environ[env] = val
+        try:
+            alt, st2 = solve_potential(cond, 0., return_stats=True)
+        finally:
+            del os.environ[env]
+        assert st2['converged'], env
+        if exact:
+            assert st2['iterations'] == st['iterations'] and np.array_equal(alt, base), env
+        else:
+            assert np.abs(alt.astype(np.float64) - base.astype(np.float64)).max() <= 2e-3, env

@@ -15,6 +15,7 @@ del dem
 ramp = (1000. * (1. - torch.arange(shape[0], device='cuda', dtype=torch.float64) / (shape[0] - 1.)))[:, None].expand(shape).contiguous()
 variants = [
     ('default', {}, {}),
+    ('no fuse', {'SSRS_AMG_NO_FUSE': '1'}, {}),
     ('nu 1,2', {'SSRS_AMG_NU': '1,2'}, {}),
     ('nu 1,1', {'SSRS_AMG_NU': '1,1'}, {}),
     ('nu 2,1', {'SSRS_AMG_NU': '2,1'}, {}),
