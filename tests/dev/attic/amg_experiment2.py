@@ -4,7 +4,7 @@ import sys, time
 sys.path.insert(0, '.')
 import numpy as np, scipy.sparse as sp, scipy.sparse.linalg as spl
 from oracle import ssrs_oracle as orc
-from tools.dev.attic.amg_experiment import build_system, gs_colors
+from tests.dev.attic.amg_experiment import build_system, gs_colors
 
 def setup(cond, dirn):
     R, C = cond.shape; n = R * C

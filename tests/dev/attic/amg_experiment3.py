@@ -5,7 +5,7 @@ import sys, time
 sys.path.insert(0, '.')
 import numpy as np, scipy.sparse as sp, scipy.sparse.linalg as spl
 from oracle import ssrs_oracle as orc
-from tools.dev.attic.amg_experiment2 import setup
+from tests.dev.attic.amg_experiment2 import setup
 
 def pairwise(A, passes=2):
     """returns aggregate id per node after `passes` rounds of strongest-neighbour matching"""

@@ -4,8 +4,8 @@ import sys, time
 sys.path.insert(0, '.')
 import numpy as np, scipy.sparse as sp, scipy.sparse.linalg as spl
 from oracle import ssrs_oracle as orc
-from tools.dev.attic.amg_experiment2 import setup
-from tools.dev.attic.amg_experiment3 import fpcg, make_cycle
+from tests.dev.attic.amg_experiment2 import setup
+from tests.dev.attic.amg_experiment3 import fpcg, make_cycle
 
 def hash32(a, b):
     x = (a.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15) ^ b.astype(np.uint64) * np.uint64(0xC2B2AE3D27D4EB4F)) & np.uint64(0xFFFFFFFF)

@@ -5,8 +5,8 @@ import sys, time
 sys.path.insert(0, '.')
 import numpy as np, scipy.sparse as sp, scipy.sparse.linalg as spl
 from oracle import ssrs_oracle as orc
-from tools.dev.attic.amg_experiment2 import setup
-from tools.dev.attic.amg_experiment4 import hierarchy
+from tests.dev.attic.amg_experiment2 import setup
+from tests.dev.attic.amg_experiment4 import hierarchy
 
 
 def make_cycle(levels, nu=2, omega=0.7, alpha=1.0, smoother='jacobi', cheb_deg=2):

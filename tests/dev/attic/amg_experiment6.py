@@ -5,9 +5,9 @@ import sys, time
 sys.path.insert(0, '.')
 import numpy as np, scipy.sparse as sp, scipy.sparse.linalg as spl
 from oracle import ssrs_oracle as orc
-from tools.dev.attic.amg_experiment2 import setup
-from tools.dev.attic.amg_experiment4 import hash32
-from tools.dev.attic.amg_experiment5 import fpcg
+from tests.dev.attic.amg_experiment2 import setup
+from tests.dev.attic.amg_experiment4 import hash32
+from tests.dev.attic.amg_experiment5 import fpcg
 
 
 def match_pass(A, rounds=8, theta=0.25, symmetric=False, permissive=0):

@@ -4,12 +4,12 @@ Galerkin coarse operators (which stay 9-point stencils: every level can be matri
 Question: how many PCG iterations to 1e-15 on the two-phase (live / dead, 1e-8 links) rasters, against
 the ~400 of the shipped pairwise aggregation?
 
-usage: python tools/dev/attic/boxmg_experiment.py c1 | g10 | g11 | synth ROWS COLS [RES] | soak N"""
+usage: python tests/dev/attic/boxmg_experiment.py c1 | g10 | g11 | synth ROWS COLS [RES] | soak N"""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np, scipy.sparse as sp, scipy.sparse.linalg as spl
 from oracle import ssrs_oracle as orc
-from tools.dev.attic.amg_experiment2 import setup
+from tests.dev.attic.amg_experiment2 import setup
 
 
 def stencil(A, shape):

@@ -3,13 +3,13 @@ potential system (candidate i): P = (I - w D_F^-1 A_F) P_tent
 links lumped into the diagonal, Galerkin coarse operators.  Aggregates: pairwise matching passes (what the
 GPU hierarchy builds) or greedy root + strong neighbours.
 
-usage: python tools/dev/attic/sa_experiment.py c1 | g10 | g11 | synth ROWS COLS [RES] | speckle F"""
+usage: python tests/dev/attic/sa_experiment.py c1 | g10 | g11 | synth ROWS COLS [RES] | speckle F"""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np, scipy.sparse as sp, scipy.sparse.linalg as spl
-from tools.dev.attic.amg_experiment2 import setup
-from tools.dev.attic.amg_experiment4 import hash32
-from tools.dev.attic.boxmg_experiment import load, pcg
+from tests.dev.attic.amg_experiment2 import setup
+from tests.dev.attic.amg_experiment4 import hash32
+from tests.dev.attic.boxmg_experiment import load, pcg
 
 
 def strong_mask(A, theta):
@@ -48,7 +48,7 @@ def greedy_aggregates(n, i, j, strong):
 
 
 def pairwise_aggregates(A, theta, passes):
-    from tools.dev.attic.amg_experiment6 import match_pass
+    from tests.dev.attic.amg_experiment6 import match_pass
     n = A.shape[0]; agg = np.arange(n); Ac = A
     dfine = A.diagonal()
     for p in range(passes):
