@@ -138,3 +138,40 @@ def test_ring_table_applies_only_to_the_reference_default_model():
     assert not ring_table_applies(1, 1.0, True, False, 0)        # trajectories: generic kernel
     assert not ring_table_applies(1, 1.0, False, True, 0)        # exact-only A/B
     assert not ring_table_applies(1, 1.0, False, False, 7)       # odd steps per launch
+
+
+def test_step_case_cuts_equal_sub_batches():
+    """More than hist_safe_tracks tracks of a case are stepped in EQUAL sub-batches (a pass lasts as long as its longest
+    track chain, so a short last sub-batch would cost a full pass for a fraction of the work), ids stay contiguous, and the
+    64-bit sum is taken whenever any rank's share needs it (simulator.py: _step_case)."""
+    import torch
+    from ssrs_amd import movmodel
+    from ssrs_amd.simulator import Simulator
+    sim = object.__new__(Simulator)
+    sim.hist_safe_tracks, sim.track_direction, sim.gridsize = 140_000, 0., (4, 5)
+    sim.track_dirn_restrict, sim.track_stochastic_nu, sim.save_tracks, sim.steps_per_launch = 1, 1., False, 0
+    calls = []
+
+    class Batch:
+        def __init__(self, n):
+            self.hist = torch.zeros((4, 5), dtype=torch.int32)
+            self.hist[0, 0] = n
+            self.lengths = torch.ones(n, dtype=torch.int32)
+            self.ends = torch.zeros((n, 2), dtype=torch.int16)
+            self.stats, self.total_points = dict(total_steps=0), n
+
+    def fake(move_dirn, sub, gridsize, *a, track_id_base=0, **kw):
+        calls.append((track_id_base, int(sub.shape[0])))
+        return Batch(int(sub.shape[0]))
+    real = movmodel.simulate_tracks
+    movmodel.simulate_tracks = fake
+    try:
+        for n, want in ((1_000_000, [125_000] * 8), (140_000, [140_000]), (140_001, [70_001, 70_000]), (300_000, [100_000] * 3)):
+            calls.clear()
+            out = sim._step_case(torch.zeros((n, 2), dtype=torch.int32), 1000, (None, None), 30, None, widest_share=n)
+            assert [c[1] for c in calls] == want, (n, calls)
+            assert [c[0] for c in calls] == [1000 + sum(want[:k]) for k in range(len(want))]
+            assert int(out.hist[0, 0]) == n and (out.hist.dtype == torch.int64) == (n > 140_000)
+            assert out.lengths.numel() == n
+    finally:
+        movmodel.simulate_tracks = real
