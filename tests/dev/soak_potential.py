@@ -62,5 +62,7 @@ if __name__ == '__main__':
             print('MISMATCH', dict(seed=seed, rows=rows, cols=cols, dirn=dirn, dead=float(dead)), st, err, res_ref, res_gpu, flush=True)
             sys.exit(1)
         n_case += 1
+        if n_case % 1000 == 0:
+            print(f'{n_case} cases, max error so far {worst:.2e}, {time.time() - t0:.0f} s', flush=True)
     print(f'soak ok: {n_case} cases, max |phi - spsolve| = {worst:.2e} (range 0..1000, f32 output), worst residual of the '
           f'f32 field in the reference system {worst_res:.1e}, iterations median {int(np.median(its))} max {max(its)}', flush=True)
