@@ -23,8 +23,10 @@
 //             order independent); once strict matching stalls, any positive
 //             coupling may pair
 //   Galerkin  P^T A P by radix-sorting (I,J) keys + reduce-by-key (hipCUB)
-//   cycle     V(2,2), damped Jacobi (omega 0.7), dense inverse on the coarsest
-//             level (<= 1024 nodes, Gauss-Jordan on the device)
+//   cycle     V(1,1) since round 4 (x = w D^-1 b, coarse correction, one sweep; V(2,2) in rounds 1-3 and as BiCGStab's
+//             fall-back), damped Jacobi (omega 0.7), level 0 in two fused stencil passes on the caller's vectors, dense
+//             inverse on the coarsest level (<= 1024 nodes, Gauss-Jordan on the device); profiles/r04_k5.md has what else
+//             was measured (black-box MG, smoothed aggregation, K-cycles, an f32 cycle)
 #include <hipcub/hipcub.hpp>
 
 #include <cmath>
