@@ -61,8 +61,12 @@ if __name__ == '__main__':
         if res_gpu > 1e-5 or err > float(os.environ.get('SOAK_ERR', '5e-3')):
             print('MISMATCH', dict(seed=seed, rows=rows, cols=cols, dirn=dirn, dead=float(dead)), st, err, res_ref, res_gpu, flush=True)
             sys.exit(1)
+        if not st['converged']:
+            slow = globals().get('slow', 0) + 1
+            globals()['slow'] = slow
+            print('not converged in 3000:', dict(seed=seed, rows=rows, cols=cols, dirn=dirn, dead=float(dead)), f"res {st['residual']:.1e} err {err:.1e}", flush=True)
         n_case += 1
         if n_case % 1000 == 0:
             print(f'{n_case} cases, max error so far {worst:.2e}, {time.time() - t0:.0f} s', flush=True)
     print(f'soak ok: {n_case} cases, max |phi - spsolve| = {worst:.2e} (range 0..1000, f32 output), worst residual of the '
-          f'f32 field in the reference system {worst_res:.1e}, iterations median {int(np.median(its))} max {max(its)}', flush=True)
+          f'f32 field in the reference system {worst_res:.1e}, iterations median {int(np.median(its))} max {max(its)}, {globals().get("slow", 0)} not converged within 3000', flush=True)

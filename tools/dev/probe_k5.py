@@ -16,6 +16,7 @@ ramp = (1000. * (1. - torch.arange(shape[0], device='cuda', dtype=torch.float64)
 variants = [
     ('default', {}, {}),
     ('no fuse', {'SSRS_AMG_NO_FUSE': '1'}, {}),
+    ('no blocks', {'SSRS_AMG_NO_BLOCKS': '1'}, {}),
     ('nu 1,2', {'SSRS_AMG_NU': '1,2'}, {}),
     ('nu 1,1', {'SSRS_AMG_NU': '1,1'}, {}),
     ('nu 2,1', {'SSRS_AMG_NU': '2,1'}, {}),
