@@ -32,7 +32,7 @@ def assemble(conductivity, move_dirn):
 if __name__ == '__main__':
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.
     t0 = time.time(); n_case = 0; worst = 0.0; its = []; worst_ratio = 0.0; worst_res = 0.0
-    master = np.random.default_rng(4242)
+    master = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 4242)       # [seconds] [master seed]
     while time.time() - t0 < budget:
         seed = int(master.integers(0, 2**31)); rng = np.random.default_rng(seed)
         rows, cols = int(rng.integers(6, 90)), int(rng.integers(6, 110))

@@ -8,7 +8,7 @@ from oracle import c_oracle
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.
 t0 = time.time(); n_case = 0; n_steps = 0
-master = np.random.default_rng(2026)
+master = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)       # [seconds] [master seed]
 while time.time() - t0 < budget:
     seed = int(master.integers(0, 2**31))
     rng = np.random.default_rng(seed)
