@@ -428,6 +428,54 @@ __global__ __launch_bounds__(kBlock) void k_cg_xr(double *__restrict__ x, double
     if (threadIdx.x == 0) s->part[4][blockIdx.x] = d;
 }
 
+// ---- the east-edge quirk as a defect of the symmetric operator (phase 2 of the AMG solve).
+// The exact operator A_q differs from the symmetric one A_s in the rows of the east-edge interior cells only: their S link
+// is weighted as a diagonal one (/ sqrt 2) and their SW link as a straight one (movmodel.py:75-79, position parity in the
+// FILTERED neighbour list).  In the D - C form of a row
+//     (A_q x - A_s x)_i = (w_S / f - w_S) (x_i - x_S) + (w_SW - w_SW / f) (x_i - x_SW),      f = sqrt 2 as f32,
+// a few thousand numbers formed from DIFFERENCES of neighbouring potentials -- no cancellation, unlike a recomputed
+// residual (whose rounding noise is ~3e-6 |b| at 5000 x 6000).  r = b - A_q x is kept up to date by
+//     r_i -= E_i(x) - E_i(x at the previous update),
+// after which the SAME preconditioned CG on A_s goes on from the corrected residual (directions restarted).  Nothing in
+// it can stagnate or break down the way BiCGStab does (soak case 342679122: restarts exhausted at 2.4e-14, the field
+// 2.6e-2 off; with this: 420 iterations, 6.5e-4), but an update only shrinks the defect by the contraction factor of
+// A_s^-1 E, ~0.1 at 5000 x 6000 -- eleven rounds and 1 460 iterations where BiCGStab takes 130 -- so it is the FALL-BACK:
+// BiCGStab first, and only a solve that BiCGStab leaves unconverged goes back to PCG's iterate and through this.
+__global__ __launch_bounds__(kBlock) void k_quirk_defect(StencilArgs a, const double *__restrict__ x,
+                                                        double *__restrict__ e_prev, double *__restrict__ r)
+{
+    const int R = a.rows, C = a.cols;
+    for (int row = blockIdx.x * kBlock + threadIdx.x; row < R; row += gridDim.x * kBlock) {
+        double e = 0.0;
+        const size_t i = static_cast<size_t>(row) * C + (C - 1);
+        if (row > 0 && row < R - 1 && C >= 2 && !a.fixed[i]) {
+            const size_t js = i - C, jsw = i - C - 1;
+            double ws, wsw;
+            if (a.rinv) {
+                const double ci = fabs(a.rinv[i]), rs = fabs(a.rinv[js]), rsw = fabs(a.rinv[jsw]);
+                ws = (ci != 0.0 && rs != 0.0) ? 2.0 / (ci + rs) : 1e-08;
+                wsw = (ci != 0.0 && rsw != 0.0) ? 2.0 / (ci + rsw) : 1e-08;
+            } else {
+                ws = pair_conductance(a.cond[i], a.cond[js]);
+                wsw = pair_conductance(a.cond[i], a.cond[jsw]);
+            }
+            e = (ws / SSRS_FAC_DIAG - ws) * (x[i] - x[js]) + (wsw - wsw / SSRS_FAC_DIAG) * (x[i] - x[jsw]);
+            r[i] -= e - e_prev[row];
+        }
+        e_prev[row] = e;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_norm2(const double *__restrict__ r, size_t n, Scalars *s)
+{
+    __shared__ double lds[kBlock / 64];
+    double d = 0.0;
+    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * kBlock)
+        d += r[i] * r[i];
+    d = block_sum(d, lds);
+    if (threadIdx.x == 0) s->part[4][blockIdx.x] = d;
+}
+
 // set-up: x0 = Dirichlet values on fixed cells / initial guess elsewhere;
 // r = b - A x0 (b = 0 on free cells), rhat = r, p = r, v = 0; partial (r, r)
 __global__ __launch_bounds__(kBlock) void k_setup(StencilArgs a, const double *__restrict__ x,
@@ -497,7 +545,7 @@ extern "C" size_t ssrs_potential_workspace_bytes(int rows, int cols)
 {
     if (rows <= 0 || cols <= 0) return 0;
     const size_t n = static_cast<size_t>(rows) * cols;
-    return (sizeof(Scalars) + 255) / 256 * 256 + 10 * vec_bytes(n) + amg_workspace_bytes(rows, cols) + 256;
+    return (sizeof(Scalars) + 255) / 256 * 256 + 11 * vec_bytes(n) + amg_workspace_bytes(rows, cols) + 256;
 }
 
 typedef struct SsrsSolveStatsInternal {
@@ -522,7 +570,7 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
     // ssrs_potential_workspace_bytes is the bound that always suffices; a smaller workspace is
     // accepted as long as the solver's own vectors fit, and the hierarchy reports "workspace
     // exhausted" if it does not (it really takes ~840 B per cell)
-    SSRS_REQUIRE(workspace_bytes >= (sizeof(Scalars) + 255) / 256 * 256 + 10 * vec_bytes(static_cast<size_t>(rows) * cols) + 512,
+    SSRS_REQUIRE(workspace_bytes >= (sizeof(Scalars) + 255) / 256 * 256 + 11 * vec_bytes(static_cast<size_t>(rows) * cols) + 512,
                  "ssrs_potential_solve: workspace too small");
     SSRS_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0,
                  "ssrs_potential_solve: workspace must be 256-byte aligned");
@@ -544,10 +592,11 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
     char *base = static_cast<char *>(workspace);
     Scalars *sc = reinterpret_cast<Scalars *>(base);
     base += (sizeof(Scalars) + 255) / 256 * 256;
-    double *vec[10];
-    for (int i = 0; i < 10; ++i) vec[i] = reinterpret_cast<double *>(base + i * vec_bytes(n));
+    double *vec[11];
+    for (int i = 0; i < 11; ++i) vec[i] = reinterpret_cast<double *>(base + i * vec_bytes(n));
     double *x = vec[0], *r = vec[1], *rhat = vec[2], *p = vec[3], *v = vec[4], *sv = vec[5], *t = vec[6];
     double *xbest = vec[7], *phat = vec[8], *shat = vec[9];
+    double *x_pcg = vec[10];               // PCG's iterate, kept for the fall-back of phase 2
     // right-preconditioned BiCGStab: M = one AMG V-cycle of the symmetric operator
     const bool use_amg = (flags & SSRS_SOLVE_NO_AMG) == 0;
     AmgHierarchy amg;
@@ -572,13 +621,13 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
     amg.symmetric = (flags & SSRS_SOLVE_ONE_SIDED) == 0;
     amg.strong_rounds = ((flags >> 8) & 15) ? ((flags >> 8) & 15) : 4;
     float setup_ms = 0.f;
-    size_t ws_used = static_cast<size_t>(10 * vec_bytes(n)) + 512;
+    size_t ws_used = static_cast<size_t>(11 * vec_bytes(n)) + 512;
     if (use_amg) {
         hipEvent_t s0, s1;
         SSRS_HIP_CHECK(hipEventCreate(&s0));
         SSRS_HIP_CHECK(hipEventCreate(&s1));
         SSRS_HIP_CHECK(hipEventRecord(s0, st));
-        char *amg_base = base + 10 * vec_bytes(n);
+        char *amg_base = base + 11 * vec_bytes(n);
         amg_base = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(amg_base) + 255) / 256 * 256);
         const size_t amg_bytes = static_cast<size_t>(static_cast<char *>(workspace) + workspace_bytes - amg_base);
         const int rc = amg_setup(amg, conductivity, fixed_mask, rows, cols, amg_base, amg_bytes, st);
@@ -613,29 +662,23 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
     double host[2] = {0.0, 0.0};
     int cg_iterations = 0;
     const bool progress = std::getenv("SSRS_PROGRESS") != nullptr;   // long solves: heartbeat on stderr
-    if (use_amg) {
-        // ---- phase 1: PCG on the symmetric operator (natural weights).  One
-        // V-cycle + one operator application per iteration; it delivers the
-        // solution up to the east-edge quirk, which phase 2 (BiCGStab on the
-        // exact operator, started from here) removes in a few iterations.
-        StencilArgs as = a;
-        as.quirk = 0;
-        hipLaunchKernelGGL(k_setup, dim3(nb), dim3(kBlock), 0, st, as, x, r, rhat, p, v, sc);
-        hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, st, sc, FIN_INIT, nb);
-        double cg_best = 1e300;
+    // preconditioned (flexible) CG on the symmetric operator A_s from the carried residual r, until |r| <= tol |b|; returns the
+    // last |r| / |b| it saw.  Phase 1 of the AMG solve, and the engine of phase 2's fall-back.
+    StencilArgs as = a;
+    as.quirk = 0;
+    bool restart_dirs = true;
+    int rc_pcg = SSRS_OK;
+    auto pcg_run = [&](double tol, int cap) -> double {
+        double cg_best = 1e300, now = 1e300;
         int stalled = 0;
-        // where PCG hands over: the exact operator's residual of the symmetric problem's solution (the quirk's
-        // defect) is ~1e-6 of the right-hand side, so BiCGStab starts from there whatever PCG reached below it
-        double pcg_tol = rel_tol;
-        if (const char *e = std::getenv("SSRS_SOLVE_PCG_TOL")) { const double v = std::atof(e); if (v > rel_tol) pcg_tol = v; }
-        while (cg_iterations < max_iterations) {
+        while (cg_iterations < cap) {
             for (int j = 0; j < 5; ++j, ++cg_iterations) {
-                // flexible CG(1): the K-cycle preconditioner is slightly non-linear,
-                // so p is A-orthogonalised explicitly against the previous direction
+                // flexible CG(1): p is A-orthogonalised explicitly against the previous direction
                 amg_apply(amg, r, phat, &sc->rnorm2, st);                                        // z = M r
                 hipLaunchKernelGGL(k_cg_dot_rz, dim3(nb), dim3(kBlock), 0, st, phat, v, n, sc);      // (z, q_prev)
                 hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, st, sc, FIN_CG_RHO, nb);
-                hipLaunchKernelGGL(k_cg_p, dim3(nb), dim3(kBlock), 0, st, p, phat, n, sc, cg_iterations == 0 ? 1 : 0);
+                hipLaunchKernelGGL(k_cg_p, dim3(nb), dim3(kBlock), 0, st, p, phat, n, sc, restart_dirs ? 1 : 0);
+                restart_dirs = false;
                 if (as.rinv)                                                                     // q = A p
                     hipLaunchKernelGGL(k_cg_apply_wave, dim3(nb), dim3(kBlock), 0, st, as, p, v, r, sc);
                 else
@@ -644,17 +687,35 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
                 hipLaunchKernelGGL(k_cg_xr, dim3(nb), dim3(kBlock), 0, st, x, r, p, v, n, sc);
                 hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, st, sc, FIN_CG_RR, nb);
             }
-            SSRS_HIP_CHECK(hipGetLastError());
-            SSRS_HIP_CHECK(hipMemcpyAsync(host, &sc->rnorm2, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
-            SSRS_HIP_CHECK(hipStreamSynchronize(st));
+            if (hipGetLastError() != hipSuccess ||
+                hipMemcpyAsync(host, &sc->rnorm2, 2 * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess) { rc_pcg = SSRS_ERR_HIP; break; }
             if (!(host[0] == host[0])) break;
-            const double now = host[1] > 0.0 ? std::sqrt(host[0] / host[1]) : 0.0;
+            now = host[1] > 0.0 ? std::sqrt(host[0] / host[1]) : 0.0;
             if (progress && (cg_iterations % 250 == 0 || std::atoi(std::getenv("SSRS_PROGRESS")) >= 2))   // (=2: every check)
                 fprintf(stderr, "[ssrs_potential_solve] PCG it %d |r|/|b| %.3e\n", cg_iterations, now);
-            if (now <= pcg_tol) break;
+            if (now <= tol) break;
             if (now < 0.9 * cg_best) { cg_best = now; stalled = 0; }
             else if (++stalled >= 100) break;          // 500 iterations without a 10 % gain
         }
+        return now;
+    };
+    bool pcg_ok = false;
+    if (use_amg) {
+        // ---- phase 1: PCG on the symmetric operator (natural weights).  One
+        // V-cycle + one operator application per iteration; it delivers the
+        // solution up to the east-edge quirk, which phase 2 (BiCGStab on the
+        // exact operator, started from here) removes in a few iterations.
+        hipLaunchKernelGGL(k_setup, dim3(nb), dim3(kBlock), 0, st, as, x, r, rhat, p, v, sc);
+        hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, st, sc, FIN_INIT, nb);
+        // where PCG hands over: the exact operator's residual of the symmetric problem's solution (the quirk's
+        // defect) is ~1e-6 of the right-hand side, so BiCGStab starts from there whatever PCG reached below it
+        double pcg_tol = rel_tol;
+        if (const char *e = std::getenv("SSRS_SOLVE_PCG_TOL")) { const double vv = std::atof(e); if (vv > rel_tol) pcg_tol = vv; }
+        const double reached = pcg_run(pcg_tol, max_iterations);
+        if (rc_pcg != SSRS_OK) return set_error(SSRS_ERR_HIP, "ssrs_potential_solve: HIP error in the PCG phase");
+        pcg_ok = reached <= rel_tol;
+        SSRS_HIP_CHECK(hipMemcpyAsync(x_pcg, x, n * sizeof(double), hipMemcpyDeviceToDevice, st));
         if (progress) {
             // what PCG's carried residual is worth: recomputed with the symmetric and with the exact operator
             for (int q = 0; q < 2; ++q) {
@@ -750,6 +811,41 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
         }
     }
     if (best < 1e300) SSRS_HIP_CHECK(hipMemcpyAsync(x, xbest, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    int dc_rounds = 0;
+    if (use_amg && !converged && pcg_ok && std::getenv("SSRS_SOLVE_NO_FALLBACK") == nullptr) {
+        // ---- fall-back of phase 2: BiCGStab did not get there (breakdowns, stagnation).  Back to PCG's iterate -- its
+        // symmetric residual is below rel_tol |b|: taken as zero -- and through the quirk's defect correction
+        // (k_quirk_defect) with the same PCG: slower than a healthy BiCGStab, but monotone.
+        if (progress) fprintf(stderr, "[ssrs_potential_solve] BiCGStab stopped at |r|/|b| %.3e after %d iterations: defect correction from PCG's iterate\n", rel, it);
+        SSRS_HIP_CHECK(hipMemcpyAsync(x, x_pcg, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+        SSRS_HIP_CHECK(hipMemsetAsync(r, 0, n * sizeof(double), st));
+        double *e_prev = rhat;
+        SSRS_HIP_CHECK(hipMemsetAsync(e_prev, 0, sizeof(double) * static_cast<size_t>(rows), st));
+        const int budget = cg_iterations + max_iterations;           // the fall-back gets an iteration budget of its own
+        double dc_last = 1e300;
+        for (; dc_rounds < 40; ++dc_rounds) {
+            hipLaunchKernelGGL(k_quirk_defect, dim3((rows + kBlock - 1) / kBlock), dim3(kBlock), 0, st, a, x, e_prev, r);
+            hipLaunchKernelGGL(k_norm2, dim3(nb), dim3(kBlock), 0, st, r, n, sc);
+            hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, st, sc, FIN_CG_RR, nb);
+            SSRS_HIP_CHECK(hipGetLastError());
+            SSRS_HIP_CHECK(hipMemcpyAsync(host, &sc->rnorm2, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+            SSRS_HIP_CHECK(hipStreamSynchronize(st));
+            const double now = host[1] > 0.0 ? std::sqrt(host[0] / host[1]) : 0.0;
+            if (progress) fprintf(stderr, "[ssrs_potential_solve] quirk update %d after %d PCG iterations: |r|/|b| %.3e (exact operator)\n", dc_rounds, cg_iterations, now);
+            dc_last = now;
+            if (now <= rel_tol) { converged = 1; rel = now; break; }
+            restart_dirs = true;
+            // an update only gains the contraction factor of A_s^-1 E (~0.1): a round solves to a tenth of where it stands
+            const double target = now * 0.05 > rel_tol ? now * 0.05 : rel_tol;
+            const double reached = pcg_run(target, budget);
+            if (rc_pcg != SSRS_OK) return set_error(SSRS_ERR_HIP, "ssrs_potential_solve: HIP error in the fall-back");
+            if (!(reached <= target) || cg_iterations >= budget) break;
+        }
+        if (!converged) {                      // keep the better of the two unfinished answers
+            if (dc_last < rel) rel = dc_last;
+            else if (best < 1e300) SSRS_HIP_CHECK(hipMemcpyAsync(x, xbest, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+        }
+    }
     if (progress) {
         // the residual the iteration carried along against the one recomputed from x
         hipLaunchKernelGGL(k_setup, dim3(nb), dim3(kBlock), 0, st, a, x, r, rhat, p, v, sc);
