@@ -44,12 +44,13 @@ RASTER_BYTES_PER_CELL = 20      # fused K1 as benchmarked: f64 DEM in (8) + f32 
 # steps/s of the stepper once the GPU is FULL of waves: what a latency-bound batch of 100k tracks is
 # measured against (`throughput_frac`).  Front-shaped batches (k_step_thr<4>): 1 M tracks per GPU on the
 # ramp, every SIMD holding several waves (profiles/r02_scale_tracks.txt, 40.6 M tracks/s x 4 850 steps).
-# Roaming batches (k_step_roam, one block of 144 KB LDS per CU): every CU holding a nearly FULL block of 256 tracks --
-# 140 000 tracks per pass with the round's final kernel (profiles/r03_roam_fill.txt: 2.84e11; more tracks need a
-# second round of blocks).  A pass takes the time of its longest track chain whatever the number of tracks, so this
-# is what the same 1.35 s could carry, not something a 100k-track pass can reach.
+# Roaming batches (k_step_roam, one block of 144 KB LDS per CU): the best the same kernel reaches in one call, 260 000 tracks
+# (512-lane blocks while ~105 000 roam, 256-lane blocks for the ~80 000 that stay to max_moves; profiles/r04_roam_fill.txt:
+# 3.64e11; rounds 3-4 quoted 2.84e11 / 3.1e11 for 140 000 tracks in 256-lane blocks).  A pass takes the time of its longest
+# track chain whatever the number of tracks, so this is what the same 1.35 s could carry, not something a 100k-track pass
+# can reach.
 THROUGHPUT_BOUND_STEPS_PER_S = 2.0e11
-ROAM_THROUGHPUT_BOUND_STEPS_PER_S = 3.1e11       # profiles/r04_roam_fill.txt: 140 000 tracks per call, this round's boxes (2.84e11 in round 3)
+ROAM_THROUGHPUT_BOUND_STEPS_PER_S = 3.6e11       # profiles/r04_roam_fill.txt: 260 000 tracks per call (3.1e11 before the 512-lane blocks)
 # Independent yardsticks of k_step_roam (not the builder's own kernel at another batch size):
 #  * VALU issue: a wave64 instruction holds its SIMD16 for 4 clocks, so 256 CUs x 4 SIMDs issue 2.4e9 / 4 x 1024 wave-instructions
 #    per second; the kernel spends 118.6 of them per wave-pair (SQ_INSTS_VALU per launch / wave-pairs per launch,
@@ -67,9 +68,9 @@ def parse():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--tracks', type=int, default=100_000, help='tracks per GPU')
-    ap.add_argument('--hist-safe-tracks', type=int, default=140_000,
+    ap.add_argument('--hist-safe-tracks', type=int, default=250_000,
                     help='tracks per sub-batch of a pass (Config.hist_safe_tracks: a uint32 histogram is safe for this many on the '
-                         'solved field, and their ~58 000 roaming survivors are one full block per CU)')
+                         'solved field, and their ~105 000 roaming tracks are one round of 512-lane blocks)')
     ap.add_argument('--resolution', type=float, default=10.0)
     ap.add_argument('--width-km', type=float, nargs=2, default=(60.0, 50.0))
     ap.add_argument('--direct', action='store_true', help='3x3 window gathers, no table')

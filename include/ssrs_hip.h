@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SSRS_VERSION 106 /* 0.1.6 */
+#define SSRS_VERSION 107 /* 0.1.7 */
 
 #define SSRS_OK 0
 #define SSRS_ERR_INVALID (-1) /* bad argument (message says which) */
@@ -227,7 +227,8 @@ typedef struct SsrsTrackStats {
                                      (near-ties, flag entries, moves out of the window, burn-in) */
     int32_t roam_shuffles;        /* times a SETTLED roaming batch had the tracks of its windows dealt afresh
                                      (every SSRS_TRACKS_ROAM_SHUFFLE batches, default 16; part of wander_sorts) */
-    int32_t reserved1;
+    int32_t roam_wide_launches;   /* of roam_launches: those run with 512-lane blocks (two list blocks of one window per CU: batches
+                                     whose survivors outnumber one round of 256-lane blocks; SSRS_TRACKS_ROAM_WIDE) */
 } SsrsTrackStats;
 
 /* Fills rows/cols/burnin/max_moves/memory/nu and zeroes the rest; `prior` must

@@ -56,7 +56,7 @@ class SsrsTrackStats(C.Structure):
                 ('block_window_ms', C.c_float), ('block_window_timed', C.c_int32),
                 ('block_window_steps', C.c_int64), ('roam_launches', C.c_int32), ('reserved0', C.c_int32),
                 ('roam_wave_pairs', C.c_int64), ('roam_slow_wave_pairs', C.c_int64),
-                ('roam_shuffles', C.c_int32), ('reserved1', C.c_int32)]
+                ('roam_shuffles', C.c_int32), ('roam_wide_launches', C.c_int32)]
 
 
 class SsrsSolveStats(C.Structure):

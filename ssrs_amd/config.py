@@ -96,11 +96,13 @@ class Config:
     steps_per_launch: int = 0           # 0 = library default
     max_tracks_file_gb: float = 64.     # refuse a <id>_tracks.pkl larger than this (tracks that wander to
     #                                     max_moves: 1 TB per 100k tracks on a solved 10 m field)
-    hist_safe_tracks: int = 140_000     # tracks per sub-batch of a case: (i) a uint32 presence histogram is safe for this many (more
-    #                                     are added up in 64 bits); (ii) on solved 10 m fields ~42 % of a batch ends up roaming, and
-    #                                     the roaming stepper holds ONE block of 256 tracks per CU: 140 000 tracks leave ~58 000
-    #                                     survivors = one full block on each of the 256 CUs (3.1e11 steps/s); a batch of 200 000
-    #                                     needs a second, 28 % full round of blocks (2.1e11; profiles/r04_roam_fill.txt)
+    hist_safe_tracks: int = 250_000     # tracks per sub-batch of a case: (i) a uint32 presence histogram is safe for this many on
+    #                                     the solved 10 m field (a trap cell takes ~1e4 visits per track; more are added up in 64
+    #                                     bits, and a sub-batch whose counts wrap all the same is stepped again as two halves);
+    #                                     (ii) ~42 % of such a batch ends up roaming, and the roaming stepper holds ONE block per
+    #                                     CU: 250 000 tracks = ~105 000 roaming at first, one round of 512-lane blocks, later
+    #                                     ~78 000 in 256-lane blocks: 2.0 s per pass = 1.27e5 tracks/s against 1.0e5 for 140 000
+    #                                     (rounds 3-4) and 1.15e5 for 300 000 (a second round of blocks; profiles/r04_roam_fill.txt)
 
     def __str__(self):
         known = {f.name for f in fields(self)}

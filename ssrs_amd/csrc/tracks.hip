@@ -676,7 +676,8 @@ struct alignas(16) TrackCtl {
     unsigned long long roam_slow;   // k_step_roam: wave-pairs in which some lane took the slow path
     unsigned long long roam_pairs;  // k_step_roam: wave-pairs run
     unsigned long long dbg_tsum, dbg_tmax, dbg_waves, dbg_slowmax;   // SSRS_TRACKS_DEBUG_ROAM: wave lifetimes of one launch
-    uint32_t roam_stop, roam_stop_pad;                               // k_step_roam: launch + 1 of the launch whose first wave is through its steps
+    uint32_t roam_stop;                                              // k_step_roam: launch + 1 of the launch whose first wave is through its steps
+    uint32_t deal_live;                                              // k_wander_windows: live tracks it found (the host picks the deal's block width from it)
     unsigned long long dbg_waits;                                    // same: polls of stepping waves that waited for a staged row
     unsigned long long dbg_span, dbg_span_max;                       // same: virtual-row span of the blocks of a front (sum << 20 | blocks; max)
 };
@@ -1137,7 +1138,7 @@ __global__ void k_ctl_init(TrackCtl *ctl, const PriorArg pr, double *__restrict_
         ctl->error = bad; ctl->par_min = 0xFFFFFFFFu; ctl->steps = 0; ctl->strays = 0; ctl->bin_done = 0; ctl->pad = 0; ctl->roam_slow = 0; ctl->roam_pairs = 0;
         ctl->dbg_tsum = ctl->dbg_tmax = ctl->dbg_waves = ctl->dbg_slowmax = 0;
         ctl->dbg_span = ctl->dbg_span_max = ctl->dbg_waits = 0;
-        ctl->roam_stop = ctl->roam_stop_pad = 0;
+        ctl->roam_stop = ctl->deal_live = 0;
     }
     if (d < 9) ctl->prior[d] = pr.v[d];
     if (d >= 9) return;
@@ -2627,20 +2628,23 @@ __global__ __launch_bounds__(kBlock) void k_fine_build(const double *__restrict_
     }
 }
 
-template <bool REV>
-__global__ __launch_bounds__(kBlock) void k_step_roam(const StepArgs a, const ThrPrior pr)
+// BT = 256: one block of list slots (rounds 3-4).  BT = 512 / 1024 ("wide", round 4): TWO / FOUR consecutive blocks of the list --
+// which the wide deal fills from one window -- share the CU's one 144-KB window with 8 / 16 waves, 2 / 4 per SIMD: a batch whose
+// survivors outnumber 256 CUs x 256 lanes then still steps in ONE round of blocks (k_deal_sorted, profiles/r04_roam_fill.txt)
+template <bool REV, int BT = kBlock>
+__global__ __launch_bounds__(BT) void k_step_roam(const StepArgs a, const ThrPrior pr)
 {
     __shared__ uint32_t s_win[kWinRows * kWinCols];
     __shared__ int s_box[4];
-    __shared__ int s_wid[kBlock / 64];
-    for (int q = threadIdx.x; q < kWinRows * kWinCols; q += kBlock) s_win[q] = 0u;
+    __shared__ int s_wid[BT / 64];
+    for (int q = threadIdx.x; q < kWinRows * kWinCols; q += BT) s_win[q] = 0u;
     if (threadIdx.x == 0) { s_box[0] = s_box[1] = 0x7fffffff; s_box[2] = s_box[3] = -1; }
     __syncthreads();
     TrackCtl *ctl = a.ctl;
     const int in_slot = a.launch & 3, out_slot = (a.launch + 1) & 3;
     const uint32_t xcd = blockIdx.x % kXcd;
     const uint32_t nlive = ctl->count[in_slot][xcd];
-    const uint32_t il = (blockIdx.x / kXcd) * kBlock + threadIdx.x;
+    const uint32_t il = (blockIdx.x / kXcd) * BT + threadIdx.x;
     const uint32_t i = xcd * a.cap + il;
     if (blockIdx.x == 0 && threadIdx.x < kXcd) ctl->count[(a.launch + 2) & 3][threadIdx.x] = 0;
 
@@ -2681,7 +2685,7 @@ __global__ __launch_bounds__(kBlock) void k_step_roam(const StepArgs a, const Th
         if ((threadIdx.x & 63) == 0) s_wid[threadIdx.x >> 6] = wid;
         __syncthreads();
         wid = 0x7fffffff;
-        for (int q = kBlock / 64 - 1; q >= 0; --q) wid = s_wid[q] != 0x7fffffff ? s_wid[q] : wid;
+        for (int q = BT / 64 - 1; q >= 0; --q) wid = s_wid[q] != 0x7fffffff ? s_wid[q] : wid;
         if (wid != 0x7fffffff && threadIdx.x == 0) {
             s_box[0] = a.wander->r0[wid]; s_box[2] = s_box[0] + kWinRows - 1;
             s_box[1] = a.wander->c0[wid]; s_box[3] = s_box[1] + kWinCols - 1;
@@ -2954,7 +2958,7 @@ __global__ __launch_bounds__(kBlock) void k_step_roam(const StepArgs a, const Th
         uint32_t wst = win_stray;
         for (int off = 32; off > 0; off >>= 1) wst += __shfl_down(wst, off);
         if ((threadIdx.x & 63) == 0) {
-            unsigned long long *r = a.dbg_buf + 8ull * (blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
+            unsigned long long *r = a.dbg_buf + 8ull * (blockIdx.x * (BT / 64) + (threadIdx.x >> 6));
             r[0] = dt; r[1] = static_cast<unsigned long long>(lanes); r[2] = n_pairs; r[3] = n_slow; r[4] = wst;
             r[5] = static_cast<unsigned long long>(win_r0); r[6] = static_cast<unsigned long long>(win_c0);
             r[7] = static_cast<uint32_t>(__popcll(__ballot(fast)));
@@ -2962,7 +2966,7 @@ __global__ __launch_bounds__(kBlock) void k_step_roam(const StepArgs a, const Th
     }
 #endif
     __syncthreads();
-    for (int q = threadIdx.x; q < kWinRows * kWinCols; q += kBlock) {
+    for (int q = threadIdx.x; q < kWinRows * kWinCols; q += BT) {
         const uint32_t n = s_win[q];
         if (n) atomicAdd(&a.hist[static_cast<uint32_t>(win_r0 + q / kWinCols) * ucols + static_cast<uint32_t>(win_c0 + q % kWinCols)], n);
     }
@@ -2978,18 +2982,18 @@ __global__ __launch_bounds__(kBlock) void k_step_roam(const StepArgs a, const Th
         if (a.end_rc) reinterpret_cast<uint32_t *>(a.end_rc)[t] = (static_cast<uint32_t>(row) & 0xFFFFu) | (static_cast<uint32_t>(col) << 16);
     }
     // one reservation per block, every lane keeps its slot, the dead leave tombstones (k_step_thr<6>)
-    __shared__ uint32_t s_surv[kBlock / 64 + 1];
+    __shared__ uint32_t s_surv[BT / 64 + 1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int nsurv = __popcll(__ballot(active));
     if (lane == 0) s_surv[wv] = static_cast<uint32_t>(nsurv);
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t tot = 0;
-        for (int q = 0; q < kBlock / 64; ++q) tot += s_surv[q];
-        s_surv[kBlock / 64] = tot ? atomicAdd(&ctl->count[out_slot][xcd], static_cast<uint32_t>(kBlock)) : 0xFFFFFFFFu;
+        for (int q = 0; q < BT / 64; ++q) tot += s_surv[q];
+        s_surv[BT / 64] = tot ? atomicAdd(&ctl->count[out_slot][xcd], static_cast<uint32_t>(BT)) : 0xFFFFFFFFu;
     }
     __syncthreads();
-    const uint32_t basei = s_surv[kBlock / 64];
+    const uint32_t basei = s_surv[BT / 64];
     if (basei != 0xFFFFFFFFu) {
         a.list_out[xcd * a.cap + basei + threadIdx.x] = active ? t : -1;
         if (active) {
@@ -3610,15 +3614,18 @@ static_assert(kXcd == 8, "k_rebalance_lists deals with j & 7 / j >> 3");
 // k_step_thr<6> keeps the blocks' slots (it reserves kBlock slots per block with a survivor and
 // writes tombstones for its dead), so the sort holds until the host asks for the next one.
 __global__ __launch_bounds__(1024) void k_wander_windows(const int32_t *__restrict__ list_in, const TrackState *__restrict__ state,
-                                                        const TrackCtl *__restrict__ ctl, int in_slot, uint32_t cap,
+                                                        TrackCtl *__restrict__ ctl, int in_slot, uint32_t cap,
                                                         int rows, int cols, WanderWindows *__restrict__ out)
 {
     __shared__ uint32_t h[kWanderBins];
     __shared__ unsigned long long s_best;
+    __shared__ uint32_t s_live;
     const int nbr = (rows + kBinRows - 1) / kBinRows, nbc = (cols + kBinCols - 1) / kBinCols;
     const int nb = nbr * nbc;                                        // <= kWanderBins (host)
     for (int q = threadIdx.x; q < nb; q += 1024) h[q] = 0;
+    if (threadIdx.x == 0) s_live = 0u;
     __syncthreads();
+    uint32_t mine = 0;
     for (uint32_t i = threadIdx.x; i < cap * kXcd; i += 1024) {
         const uint32_t x = i / cap, il = i - x * cap;
         if (il >= ctl->count[in_slot][x]) continue;
@@ -3626,8 +3633,13 @@ __global__ __launch_bounds__(1024) void k_wander_windows(const int32_t *__restri
         if (t < 0) continue;
         const int32_t pos = state[t].pos;
         atomicAdd(&h[((pos & 0xFFFF) / kBinRows) * nbc + ((pos >> 16) & 0xFFFF) / kBinCols], 1u);
+        ++mine;
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_live, mine);
     __syncthreads();
+    if (threadIdx.x == 0) ctl->deal_live = s_live;
     int n = 0;
     for (; n < kWanderWindows; ++n) {
         if (threadIdx.x == 0) s_best = 0ull;
@@ -3690,13 +3702,15 @@ __global__ __launch_bounds__(kBlock) void k_wander_keys(const int32_t *__restric
 
 __global__ __launch_bounds__(1024) void k_deal_sorted(const uint32_t *__restrict__ sorted_keys, const int32_t *__restrict__ sorted,
                                                      int32_t *__restrict__ list_out, TrackCtl *ctl, int out_slot, int zero_slot, uint32_t cap,
-                                                     int contiguous)
+                                                     int contiguous, int width)
 {
     // run of key k: [lo[k], lo[k + 1]) in the sorted order, dealt from position off[k] on
     __shared__ uint32_t lo[kWanderWindows + 3], off[kWanderWindows + 3];
     __shared__ uint32_t s_fill;
     const uint32_t slots = cap * kXcd;
-    constexpr uint32_t kRun = kXcd * kBlock;
+    // width 2 / 4 (k_step_roam<REV, 512 / 1024>): a window's run is whole groups of `width` blocks and every list holds whole groups
+    const uint32_t uw = static_cast<uint32_t>(width);
+    const uint32_t kRun = kXcd * kBlock * uw;
     if (threadIdx.x <= kWanderWindows + 2) {
         // first index whose key is >= threadIdx.x
         uint32_t a = 0, b = slots;
@@ -3715,7 +3729,15 @@ __global__ __launch_bounds__(1024) void k_deal_sorted(const uint32_t *__restrict
         const uint32_t live = lo[kWanderWindows + 1];
         uint32_t fill = kBlock;
         if (contiguous) {
-            fill = (live + kDealBlocks - 1) / kDealBlocks;
+            // the blocks must stay under the 256 CUs x blocks per CU (a block beyond the first round of a launch finds the
+            // stop flag up and waits for the others to finish the pass): kDealBlocks + one partial block per window IN USE
+            // (round 4: the allowance of the unused ones goes to the deal, 246 instead of 232 blocks with two basins =
+            // 63 000 instead of 59 392 live tracks in one round) + the padding to whole blocks of every list.
+            // Wide: 216 groups + one per window + the padding
+            uint32_t in_use = 0;
+            for (int k = 0; k <= kWanderWindows; ++k) in_use += lo[k + 1] > lo[k] ? 1u : 0u;
+            const uint32_t deal_blocks = uw > 1u ? uw * 216u : kDealBlocks + (kWanderWindows + 1u - in_use);
+            fill = (live + deal_blocks - 1) / deal_blocks;
             fill = fill < 64u ? 64u : (fill > kBlock ? kBlock : fill);
         }
         uint32_t run = 0;
@@ -3723,7 +3745,8 @@ __global__ __launch_bounds__(1024) void k_deal_sorted(const uint32_t *__restrict
             run = 0;
             for (int k = 0; k <= kWanderWindows; ++k) {              // (key kWanderWindows + 1 = dead: not dealt)
                 off[k] = run;
-                const uint32_t blocks = (lo[k + 1] - lo[k] + fill - 1) / fill;
+                uint32_t blocks = (lo[k + 1] - lo[k] + fill - 1) / fill;
+                blocks = (blocks + uw - 1u) / uw * uw;
                 // round-robin deal: a window's run is whole blocks of EVERY list
                 run += contiguous ? blocks * kBlock : (blocks * kBlock + kRun - 1) / kRun * kRun;
             }
@@ -4333,6 +4356,14 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
     const bool lds_rows = lds_rows_env != nullptr;
     a.lr_wait = (lds_rows && std::atoi(lds_rows_env) == 2) ? 1 : 0;
     bool roam_ready = false;
+    // wide roaming blocks (k_step_roam<REV, 512>): chosen at a deal when more tracks are alive than one round of 256-lane blocks
+    // holds (SSRS_TRACKS_ROAM_WIDE=<live tracks from which on>, 0: never, 1: always), kept until the next deal
+    int roam_width = 1;                      // 1, 2, 4: blocks of 256, 512, 1024 lanes
+    long long roam_wide_from = static_cast<long long>(kDealBlocks + kWanderWindows - 2) * kBlock + 1;   // (63 233: what a narrow deal with three windows in use holds)
+    if (const char *e = std::getenv("SSRS_TRACKS_ROAM_WIDE")) roam_wide_from = std::atoll(e);
+    int roam_width_forced = 0;               // SSRS_TRACKS_ROAM_WIDTH=1|2|4: that width at every deal (A/B)
+    if (const char *e = std::getenv("SSRS_TRACKS_ROAM_WIDTH")) { const int w = std::atoi(e); if (w == 1 || w == 2 || w == 4) roam_width_forced = w; }
+    int roam_wide_launches = 0;
     int roam_launches = 0, stable_roam = 0, since_shuffle = 0, roam_shuffles = 0;
     bool sort_is_periodic = false;
     int roam_shuffle = 16;                   // batches between two shuffles of a settled roaming batch (SSRS_TRACKS_ROAM_SHUFFLE, 0: never)
@@ -4427,8 +4458,29 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                 rc = set_error(SSRS_ERR_HIP, "wander sort failed");
                 break;
             }
+            // block width of the deal: 512-lane blocks when more tracks are alive than one round of 256-lane blocks holds (216 x 512
+            // in one round; beyond that several rounds either way, 512 lanes never slower: profiles/r04_roam_fill.txt; 1024-lane
+            // blocks measured 3-4x slower than either -- four waves per SIMD and a launch that ends with its first wave --,
+            // SSRS_TRACKS_ROAM_WIDTH=4 keeps the A/B).  The lists' lengths count tombstones and padding, so the width goes by
+            // the live tracks k_wander_windows has just counted: one word read back synchronously, and only when the lists are
+            // long enough for the question to arise
+            roam_width = 1;
+            if (roam_ok && deal_contiguous) {
+                if (roam_wide_from == 1) {
+                    roam_width = 2;
+                } else if (roam_wide_from > 1 && static_cast<long long>(prev_total) >= roam_wide_from) {
+                    uint32_t *word = &host_counts[kFinalSlot];
+                    if (hipMemcpyAsync(word, &ws.ctl->deal_live, sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                        hipStreamSynchronize(st) != hipSuccess) {
+                        rc = set_error(SSRS_ERR_HIP, "live-count read-back at the deal failed");
+                        break;
+                    }
+                    if (static_cast<long long>(*word) >= roam_wide_from) roam_width = 2;
+                }
+                if (roam_width_forced) roam_width = roam_width_forced;
+            }
             hipLaunchKernelGGL(k_deal_sorted, dim3(64), dim3(1024), 0, st, k1, sorted, ws.list[(launch + 1) & 1], ws.ctl,
-                               (launch + 1) & 3, (launch + 2) & 3, ws.cap, deal_contiguous ? 1 : 0);
+                               (launch + 1) & 3, (launch + 2) & 3, ws.cap, deal_contiguous ? 1 : 0, roam_width);
             ++launch;
             ++wander_sorts;
             want_wander_sort = false;
@@ -4441,8 +4493,9 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
             // the padded deal makes the lists LONGER (each window's run is rounded up to whole blocks of
             // every list): raise the bound now, and let no batch queued before this point lower it
             // (thinned blocks: at most kDealBlocks + one per window + the padding, 264 blocks = 33 per list)
-            unsigned long long padded = static_cast<unsigned long long>(upper) + (kWanderWindows + 1ull) * kBlock;
-            constexpr unsigned long long kDealPerList = (kDealBlocks + kWanderWindows + 1) / kXcd + 3;      // 34 blocks per list (144 rows)
+            const unsigned long long wf = static_cast<unsigned long long>(roam_width);    // (wide: runs are whole groups of blocks)
+            unsigned long long padded = static_cast<unsigned long long>(upper) + (kWanderWindows + 1ull) * kBlock * wf;
+            const unsigned long long kDealPerList = (wf * kDealBlocks + wf * (kWanderWindows + 1)) / kXcd + 3;      // 34 blocks per list (144 rows)
             if (deal_contiguous && padded < kDealPerList * kBlock) padded = kDealPerList * kBlock;
             upper = padded > ws.cap ? ws.cap : static_cast<uint32_t>(padded);
             upper_from = batches;
@@ -4604,7 +4657,18 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                         batch_block_window = is_block_window = true;
                         if (roam_ok && roam_ready) {
                             ++roam_launches;
-                            if (rev) hipLaunchKernelGGL(k_step_roam<true>, dim3(blocks), dim3(kBlock), 0, st, a, thr_prior);
+                            if (roam_width > 1) {
+                                const unsigned bt = static_cast<unsigned>(roam_width) * kBlock;
+                                const unsigned wblocks = kXcd * ((upper + bt - 1) / bt);
+                                ++roam_wide_launches;
+                                if (roam_width == 2) {
+                                    if (rev) hipLaunchKernelGGL((k_step_roam<true, 2 * kBlock>), dim3(wblocks), dim3(bt), 0, st, a, thr_prior);
+                                    else hipLaunchKernelGGL((k_step_roam<false, 2 * kBlock>), dim3(wblocks), dim3(bt), 0, st, a, thr_prior);
+                                } else {
+                                    if (rev) hipLaunchKernelGGL((k_step_roam<true, 4 * kBlock>), dim3(wblocks), dim3(bt), 0, st, a, thr_prior);
+                                    else hipLaunchKernelGGL((k_step_roam<false, 4 * kBlock>), dim3(wblocks), dim3(bt), 0, st, a, thr_prior);
+                                }
+                            } else if (rev) hipLaunchKernelGGL(k_step_roam<true>, dim3(blocks), dim3(kBlock), 0, st, a, thr_prior);
                             else hipLaunchKernelGGL(k_step_roam<false>, dim3(blocks), dim3(kBlock), 0, st, a, thr_prior);
 #ifdef SSRS_DEBUG_WAVE_DUMP
                             if (a.debug_roam && launch == SSRS_DEBUG_WAVE_DUMP && a.dbg_buf) {
@@ -4870,6 +4934,7 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
         stats->wander_sorts = wander_sorts;
         stats->roam_launches = roam_launches;
         stats->roam_shuffles = roam_shuffles;
+        stats->roam_wide_launches = roam_wide_launches;
         stats->roam_wave_pairs = static_cast<int64_t>(host_ctl.roam_pairs);
         stats->roam_slow_wave_pairs = static_cast<int64_t>(host_ctl.roam_slow);
         stats->reserved0 = static_cast<int32_t>(host_ctl.pad);                   // near-ties settled by the fine table

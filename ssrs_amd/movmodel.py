@@ -448,7 +448,8 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
                            roam_fine_settled=int(stats.reserved0),
                            roam_wave_pairs=int(stats.roam_wave_pairs),
                            roam_slow_wave_pairs=int(stats.roam_slow_wave_pairs),
-                           roam_shuffles=int(stats.roam_shuffles)))
+                           roam_shuffles=int(stats.roam_shuffles),
+                           roam_wide_launches=int(stats.roam_wide_launches)))
 
 
 def generate_simulated_tracks(move_dirn, start_location, grid_shape, memory_parameter=1,

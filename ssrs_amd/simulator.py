@@ -556,12 +556,15 @@ class Simulator(Config):
                         collect(f.result() for f in done)
                 collect(f.result() for f in pending)
 
+    _MIN_SPLIT_TRACKS = 64          # a wrapped sub-batch smaller than twice this is an error, not a split
+
     def _step_case(self, my_starts, lo, fields, seed, use_table, widest_share=None):
         """The tracks of one (case, realisation) on this rank.  The presence histogram is uint32 (the
         reference's int16 wraps at 32 767, movmodel.py:415): a trap cell of the solved 10 m field takes
         ~1e9 visits per 100k tracks, so more than `hist_safe_tracks` tracks are stepped in sub-batches whose
         histograms are added up in 64 bits (K4 takes that form), and every sub-batch is checked by its
-        checksum -- the counts must add up to the points of its tracks; a wrapped cell leaves 2^32 missing."""
+        checksum -- the counts must add up to the points of its tracks; a wrapped cell leaves 2^32 missing, and that
+        sub-batch is stepped again as two halves (HistogramOverflow only below _MIN_SPLIT_TRACKS tracks)."""
         from .distributed import HistogramOverflow
         n = int(my_starts.shape[0])
         safe = max(1, int(self.hist_safe_tracks))
@@ -570,8 +573,12 @@ class Simulator(Config):
         # short last sub-batch would cost a full pass's time for a fraction of the work
         step = max(1, -(-n // max(1, -(-n // safe))))
         parts, wide, stats = [], None, None
-        for t0 in range(0, max(n, 1), step):
-            sub = my_starts[t0:t0 + step]
+        # (start, length) of the sub-batches still to step, in track-id order; one whose uint32 counts wrapped is stepped
+        # again as two halves, added up in 64 bits like the rest
+        todo = [(t0, min(step, n - t0)) for t0 in range(0, max(n, 1), step)]
+        while todo:
+            t0, m = todo.pop(0)
+            sub = my_starts[t0:t0 + m]
             b = movmodel.simulate_tracks(
                 self.track_direction, sub, self.gridsize, self.track_dirn_restrict,
                 self.track_stochastic_nu, fields[0], fields[1], seed=seed, track_id_base=lo + t0,
@@ -579,10 +586,20 @@ class Simulator(Config):
                 steps_per_launch=self.steps_per_launch)
             counted = int((b.hist.view(torch.int32).to(torch.int64) & 0xFFFFFFFF).sum().item())
             if counted != b.total_points:
-                raise HistogramOverflow(
-                    f'presence histogram: {b.total_points - counted} visits are missing from the uint32 counts of '
-                    f'{int(sub.shape[0])} tracks (a cell passed 2^32 - 1): lower Config.hist_safe_tracks '
-                    f'(now {self.hist_safe_tracks})')
+                if m < 2 * self._MIN_SPLIT_TRACKS:
+                    raise HistogramOverflow(
+                        f'presence histogram: {b.total_points - counted} visits are missing from the uint32 counts of '
+                        f'{m} tracks (a cell passed 2^32 - 1)')
+                import warnings
+                warnings.warn(f'presence histogram: the uint32 counts of a sub-batch of {m} tracks wrapped '
+                              f'({b.total_points - counted} visits missing); stepping it again as two halves '
+                              f'(Config.hist_safe_tracks = {self.hist_safe_tracks} is too many for this field)', RuntimeWarning)
+                todo[:0] = [(t0, m // 2), (t0 + m // 2, m - m // 2)]
+                if not widen and parts:                       # (cannot happen: without `widen` there is one sub-batch)
+                    raise HistogramOverflow('presence histogram: sub-batch wrapped after others were kept in 32 bits')
+                widen = True
+                del b
+                continue
             parts.append(b)
             if widen:
                 h64 = b.hist.view(torch.int32).to(torch.int64) & 0xFFFFFFFF

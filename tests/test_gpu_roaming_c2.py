@@ -103,7 +103,8 @@ def test_uncapped_roaming_tracks_vs_oracle_at_c2(c2_field):
     ~130 pair-table launches of 65 536 steps, the stop flag, the periodic re-deal -- and eight contiguous id
     ranges of 64 tracks (finishers, tracks that leave a basin after 1e5..7e6 moves, tracks at max_moves) are
     stepped uncapped by the C oracle under their global ids (~1.3e9 steps): lengths and end cells must be equal.
-    Then the same batch with the re-deal after EVERY settled batch and with none at all: identical integers."""
+    Then the same batch with the re-deal after EVERY settled batch and with none at all, and with 512- / 1024-lane blocks:
+    identical integers."""
     import os
     from ssrs_amd import movmodel
     from oracle import c_oracle
@@ -134,6 +135,16 @@ def test_uncapped_roaming_tracks_vs_oracle_at_c2(c2_field):
         assert (alt.stats['roam_shuffles'] > st['roam_shuffles']) if shuffle == '1' else (alt.stats['roam_shuffles'] == 0), \
             (shuffle, alt.stats['roam_shuffles'], st['roam_shuffles'])
         assert torch.equal(alt.lengths, got.lengths) and torch.equal(alt.ends, got.ends) and torch.equal(alt.hist, got.hist), shuffle
+    # 512- and 1024-lane blocks (two / four list blocks of one window per CU: what a batch with more survivors than one
+    # round of 256-lane blocks gets, forced here): identical integers
+    for width in ('2', '4'):
+        os.environ['SSRS_TRACKS_ROAM_WIDTH'] = width
+        try:
+            alt = movmodel.simulate_tracks(0., starts, SHAPE, 1, 1., f['upd'], f['pot'], seed=30)
+        finally:
+            del os.environ['SSRS_TRACKS_ROAM_WIDTH']
+        assert alt.stats['roam_wide_launches'] > 50 and st['roam_wide_launches'] == 0, (width, alt.stats)
+        assert torch.equal(alt.lengths, got.lengths) and torch.equal(alt.ends, got.ends) and torch.equal(alt.hist, got.hist), width
 
 
 def test_config2_share_125k_tracks_on_the_solved_field(c2_field):

@@ -73,10 +73,10 @@ def test_simulator_streams_the_pickle_and_refuses_absurd_sizes(gpu, tmp_path):
 def test_single_rank_histogram_guard_and_64_bit_sub_batches(gpu, tmp_path):
     """A narrow, deep well in the potential (written into the <id>_potential.npy cache of the file contract,
     simulator.py:262-272) traps every track until max_moves = 2.25e6: 80 000 tracks put 1.8e11 visits onto
-    ~180 cells, 2.7 % of them (4.8e9 > 2^32) onto the hottest.  One uint32 histogram wraps -- the checksum guard raises;
-    sub-batches of 20 000 tracks are added up in 64 bits and the counts add up to the points of the tracks."""
+    ~180 cells, 2.7 % of them (4.8e9 > 2^32) onto the hottest.  One uint32 histogram wraps -- the checksum guard sees it, warns
+    and steps the batch again as two halves; sub-batches of 20 000 tracks (Config.hist_safe_tracks) never wrap; both ways the
+    counts are added up in 64 bits and add up to the points of the tracks, cell for cell the same."""
     from ssrs_amd import Config, Simulator
-    from ssrs_amd.distributed import HistogramOverflow
     rows = cols = 3000
     cfg = Config(run_name='w', out_dir=str(tmp_path), sim_seed=5, region_width_km=(30., 30.), resolution=10.,
                  track_count=80_000, track_start_region=(14.5, 15.5, 14., 14.6), track_direction=0., save_tracks=False)
@@ -86,8 +86,10 @@ def test_single_rank_histogram_guard_and_64_bit_sub_batches(gpu, tmp_path):
     d2 = (rr - 1500.) ** 2 + (cc - 1500.) ** 2
     pot = (1000. * (1. - rr / (rows - 1.)) + 4.0 * np.sqrt(d2) - 3000. * np.exp(-d2 / (2. * 2.5 ** 2))).astype(np.float32)
     np.save(os.path.join(sim.mode_data_dir, 's10d270_d0_t75_fluidflow_r0_potential.npy'), pot)
-    with pytest.raises(HistogramOverflow, match='missing'):
+    with pytest.warns(RuntimeWarning, match='wrapped'):
         sim.simulate_tracks()
+    halves = sim._presence_counts[('s10d270', 0)]
+    assert halves.dtype == torch.int64 and int(halves.max().item()) > 2 ** 32
     safe = Simulator(replace(cfg, run_name='w2', hist_safe_tracks=20_000), terrain=flat)
     np.save(os.path.join(safe.mode_data_dir, 's10d270_d0_t75_fluidflow_r0_potential.npy'), pot)
     safe.simulate_tracks()
@@ -96,5 +98,6 @@ def test_single_rank_histogram_guard_and_64_bit_sub_batches(gpu, tmp_path):
     steps = sum(st['total_steps'] for st in [safe.last_stats[('s10d270', 0)]])
     assert int(hist.sum().item()) == steps + 80_000
     assert int(hist.max().item()) > 2 ** 32                  # the cell that wrapped in the single histogram
+    assert torch.equal(hist, halves)
     out = safe.compute_presence_map(radius=100.)
     assert out.dtype == np.float32 and float(out.max()) == 1.0 and np.isfinite(out).all()

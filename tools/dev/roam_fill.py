@@ -27,5 +27,5 @@ for n in counts:
     alive = int((o.lengths - 1 >= (cap or 7_500_000)).sum())
     dig = hashlib.sha256(o.lengths.cpu().numpy().tobytes() + o.ends.cpu().numpy().tobytes() + o.hist.cpu().numpy().tobytes()).hexdigest()[:12]
     print(f'{n} tracks, {alive} at the cap: wall {wall * 1e3:.0f} ms, {n / wall:.0f} tracks/s, block-window launches {st["block_window_launches"]} '
-          f'(pair table {st["roam_launches"]}), {st["block_window_steps"] / max(st["block_window_ms"], 1e-9) * 1e3:.3e} steps/s in them, '
+          f'(pair table {st["roam_launches"]}, wide {st["roam_wide_launches"]}), {st["block_window_steps"] / max(st["block_window_ms"], 1e-9) * 1e3:.3e} steps/s in them, '
           f'wave-pairs/launch/32768 {st["roam_wave_pairs"] / max(st["roam_launches"], 1) / 32768:.0f}, digest {dig}', flush=True)
