@@ -175,3 +175,44 @@ def test_step_case_cuts_equal_sub_batches():
             assert out.lengths.numel() == n
     finally:
         movmodel.simulate_tracks = real
+
+
+def test_step_case_splits_a_sub_batch_whose_uint32_counts_wrapped():
+    """A sub-batch whose histogram checksum is short (a cell passed 2^32 - 1) is stepped again as two halves, in track-id
+    order, with a warning, and everything is added up in 64 bits; below Simulator._MIN_SPLIT_TRACKS it is an error
+    (simulator.py: _step_case)."""
+    import torch
+    from ssrs_amd import movmodel
+    from ssrs_amd.distributed import HistogramOverflow
+    from ssrs_amd.simulator import Simulator
+    sim = object.__new__(Simulator)
+    sim.hist_safe_tracks, sim.track_direction, sim.gridsize = 250_000, 0., (4, 5)
+    sim.track_dirn_restrict, sim.track_stochastic_nu, sim.save_tracks, sim.steps_per_launch = 1, 1., False, 0
+    calls = []
+    limit = [30_000]
+
+    class Batch:
+        def __init__(self, n):
+            self.hist = torch.zeros((4, 5), dtype=torch.int32)
+            self.hist[0, 0] = n if n <= limit[0] else n - 7          # more than `limit` tracks: 7 visits "missing"
+            self.lengths = torch.ones(n, dtype=torch.int32)
+            self.ends = torch.zeros((n, 2), dtype=torch.int16)
+            self.stats, self.total_points = dict(total_steps=0), n
+
+    def fake(move_dirn, sub, gridsize, *a, track_id_base=0, **kw):
+        calls.append((track_id_base, int(sub.shape[0])))
+        return Batch(int(sub.shape[0]))
+    real = movmodel.simulate_tracks
+    movmodel.simulate_tracks = fake
+    try:
+        with pytest.warns(RuntimeWarning, match='wrapped'):
+            out = sim._step_case(torch.zeros((100_000, 2), dtype=torch.int32), 500, (None, None), 30, None, widest_share=100_000)
+        kept = [c for c in calls if c[1] <= limit[0]]
+        assert [c[1] for c in kept] == [25_000] * 4 and [c[0] for c in kept] == [500, 25_500, 50_500, 75_500]
+        assert [c[1] for c in calls if c[1] > limit[0]] == [100_000, 50_000, 50_000]
+        assert out.hist.dtype == torch.int64 and int(out.hist[0, 0]) == 100_000 and out.lengths.numel() == 100_000
+        limit[0] = 0                                                  # every batch wraps: ends in the error, not in a loop
+        with pytest.warns(RuntimeWarning), pytest.raises(HistogramOverflow, match='missing'):
+            sim._step_case(torch.zeros((1000, 2), dtype=torch.int32), 0, (None, None), 30, None, widest_share=1000)
+    finally:
+        movmodel.simulate_tracks = real
