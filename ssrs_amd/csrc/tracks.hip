@@ -4359,7 +4359,7 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
     // wide roaming blocks (k_step_roam<REV, 512>): chosen at a deal when more tracks are alive than one round of 256-lane blocks
     // holds (SSRS_TRACKS_ROAM_WIDE=<live tracks from which on>, 0: never, 1: always), kept until the next deal
     int roam_width = 1;                      // 1, 2, 4: blocks of 256, 512, 1024 lanes
-    long long roam_wide_from = static_cast<long long>(kDealBlocks + kWanderWindows - 2) * kBlock + 1;   // (63 233: what a narrow deal with three windows in use holds)
+    long long roam_wide_from = static_cast<long long>(kDealBlocks + kWanderWindows - 2) * kBlock + 1;   // (62 977: one more than a narrow deal with three windows in use holds, 246 blocks)
     if (const char *e = std::getenv("SSRS_TRACKS_ROAM_WIDE")) roam_wide_from = std::atoll(e);
     int roam_width_forced = 0;               // SSRS_TRACKS_ROAM_WIDTH=1|2|4: that width at every deal (A/B)
     if (const char *e = std::getenv("SSRS_TRACKS_ROAM_WIDTH")) { const int w = std::atoi(e); if (w == 1 || w == 2 || w == 4) roam_width_forced = w; }
