@@ -3760,7 +3760,7 @@ __global__ __launch_bounds__(1024) void k_deal_sorted(const uint32_t *__restrict
             // no room for the padding (nearly every slot is live): dense deal, blocks may mix windows
             run = 0;
             for (int k = 0; k <= kWanderWindows + 1; ++k) { off[k] = run; if (k <= kWanderWindows) run += lo[k + 1] - lo[k]; }
-            off[kWanderWindows + 1] = (run + kRun - 1) / kRun * kRun;
+            off[kWanderWindows + 1] = (run + kRun - 1) / kRun * kRun;   // (<= slots: cap is a multiple of 4 blocks, workspace_layout)
             off[kWanderWindows + 2] = 1;                             // dense
         } else {
             off[kWanderWindows + 2] = 0;
@@ -3836,8 +3836,9 @@ static size_t sort_temp_size(int64_t n)
 static size_t workspace_layout(int64_t n, char *base, Workspace *ws)
 {
     size_t off = 0;
-    // kXcd lists of cap slots each; cap is a whole number of blocks
-    const size_t cap = align_up((static_cast<size_t>(n) + kXcd - 1) / kXcd, kBlock);
+    // kXcd lists of cap slots each; cap is a whole number of the widest blocks (k_step_roam<REV, 1024>: the wide deal rounds
+    // every list up to whole groups of blocks, and its dense fall-back must still fit)
+    const size_t cap = align_up((static_cast<size_t>(n) + kXcd - 1) / kXcd, 4 * kBlock);
     const size_t slots = cap * kXcd;
     if (ws) ws->cap = static_cast<uint32_t>(cap);
     if (ws) ws->ctl = reinterpret_cast<TrackCtl *>(base + off);

@@ -1037,3 +1037,24 @@ def test_block_windows_when_nearly_every_track_is_trapped(gpu):
         assert np.array_equal(res.lengths.cpu().numpy(), ref['lengths'])
         assert np.array_equal(res.ends.cpu().numpy(), ref['ends'])
         assert np.array_equal(res.hist.cpu().numpy().view(np.uint32), ref['hist'])
+    # the same with 512- / 1024-lane roaming blocks forced (whole groups of 2 / 4 list blocks per window; found by the soak:
+    # 9 000 tracks made lists of 5 blocks, whose dense deal rounded up to 6 and ran past the list -- lists are whole groups
+    # of 4 blocks since), on this batch and on one whose size is no multiple of anything
+    rng = np.random.default_rng(4)
+    n2 = 9000
+    starts2 = np.stack([rng.integers(2, 10, n2), rng.integers(5, cols - 5, n2)], 1)
+    ref2 = c_oracle.simulate_tracks(0., starts2, (rows, cols), 1, 1., upd, pot, seed=6, max_moves=cap, want_traj=False)
+    for width in ('2', '4'):
+        os.environ['SSRS_TRACKS_ROAM_WIDTH'] = width
+        os.environ['SSRS_TRACKS_FIXED_STEPS'] = '1'
+        try:
+            for st_, rf_ in ((starts, ref), (starts2, ref2)):
+                for scattered in (False, True):
+                    res = movmodel.simulate_tracks(0., st_, (rows, cols), 1, 1., upd, pot, seed=6, use_table=True, thr=True,
+                                                   max_moves=cap, steps_per_launch=64, scattered=scattered)
+                    assert res.stats['roam_wide_launches'] > 0, (width, scattered, res.stats)
+                    assert np.array_equal(res.lengths.cpu().numpy(), rf_['lengths']), (width, scattered)
+                    assert np.array_equal(res.ends.cpu().numpy(), rf_['ends']), (width, scattered)
+                    assert np.array_equal(res.hist.cpu().numpy().view(np.uint32), rf_['hist']), (width, scattered)
+        finally:
+            del os.environ['SSRS_TRACKS_ROAM_WIDTH'], os.environ['SSRS_TRACKS_FIXED_STEPS']
