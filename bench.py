@@ -84,6 +84,9 @@ def parse():
     ap.add_argument('--solve-iterations', type=int, default=2000)
     ap.add_argument('--stand-in-steps', type=int, default=10,
                     help='timed passes of the ramp stand-in leg (after the timed region; 0 = skip)')
+    ap.add_argument('--full-chip-tracks', type=int, default=250_000,
+                    help='tracks of the `full_chip` leg: ONE pass of that many tracks on the solved field after the timed region '
+                         '(what the stepper carries once the batch fills the SIMDs; default-variant runs at N=1 only; 0 = skip)')
     ap.add_argument('--no-chain-probe', action='store_true',
                     help='skip the 16 384-track dependent-chain measurement (profiling runs: keeps per-kernel averages clean)')
     ap.add_argument('--ref-cpu-seconds', type=float, default=2.0,
@@ -667,6 +670,30 @@ def main():
             'what': 'the same pass on the linear-ramp stand-in potential (the headline of rounds 1-2): the batch crosses '
                     'the raster as one front; after the timed region, not part of `value`',
         }
+    if world == 1 and solved and default_variant and args.full_chip_tracks > 0:
+        # what the same stepper carries when the batch fills the chip (one call of 250 000 tracks: 512-lane roaming blocks while
+        # ~105 000 tracks roam, 256-lane blocks after): one warm-up-free pass, histogram checked by its checksum
+        nf = int(args.full_chip_tracks)
+        np.random.seed(seed)
+        fr, fc = movmodel.get_starting_indices(nf, (5, 55, 1, 2), 'random', tuple(args.width_km), res)
+        leg = Passes(args, mods, dem, pot, torch.from_numpy(np.stack([fr, fc], 1).astype(np.int32)).to(dev), 0, gridsize, res, seed, 1, dev)
+        el3, last3 = leg.run(1, 0)
+        l3 = last3.lengths.cpu().numpy().astype(np.int64)
+        st3 = last3.stats
+        h3 = leg.last_hist
+        counted = int((h3.to(torch.int64) & (0xFFFFFFFF if h3.dtype == torch.int32 else -1)).sum().item())
+        out['full_chip'] = {
+            'tracks': nf, 'value': nf / el3, 'unit': 'tracks/s', 'ms_per_step': el3 * 1e3, 'steps_per_s': leg.acc['steps'] / el3,
+            'steps_per_s_in_roam_kernels': (leg.acc['block_window_steps'] / (leg.acc['block_window_ms'] * 1e-3)
+                                            if leg.acc['block_window_ms'] > 0 else None),
+            'roam_launches': int(st3.get('roam_launches', 0)), 'roam_wide_launches': int(st3.get('roam_wide_launches', 0)),
+            'share_at_max_moves': float(np.mean(l3 - 1 >= max_moves)),
+            'histogram_counts_every_point_once': bool(counted == int(l3.sum())),
+            'what': 'one pass of this many tracks in ONE call on the same field, after the timed region and not part of `value`: '
+                    'the stepper with two waves per SIMD while more tracks roam than 256 CUs x 256 lanes hold '
+                    '(k_step_roam<REV, 512>), narrow blocks after (profiles/r04_roam_fill.txt)',
+        }
+        del leg, last3, h3
     if world == 1 and args.cpu_seconds > 0:
         cap = args.cpu_cap if solved else None
         oro_gpu, upd_gpu = layers.updraft_from_dem(dem, res, 10.0, 270.0, threshold=0.75)
