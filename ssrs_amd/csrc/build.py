@@ -81,6 +81,8 @@ def build_variant(defines, tag, sources=('amg.hip', 'potential.hip'), travel=Fal
 if __name__ == '__main__':
     if '--win72' in sys.argv:         # 72-row block windows: two k_step_roam blocks per CU (A/B, results identical)
         print(build_variant(['SSRS_WIN_ROWS=72'], 'win72', sources=('tracks.hip',), travel=True))
+    elif '--probe-nostray' in sys.argv:   # k_step_roam without the strays' global atomics (timing only: wrong histogram)
+        print(build_variant(['SSRS_PROBE_NO_STRAY_ATOMICS'], 'probe_nostray', sources=('tracks.hip',), travel=True))
     elif '--amg-f32' in sys.argv:       # the f32 V-cycle measured and rejected in round 4 (stalls at 1e-8: amg.h)
         print(build_variant(['SSRS_AMG_CYCLE_F32'], 'amg_f32'))
     elif '--probe-k3' in sys.argv:      # binning-kernel timing probes (wrong histograms: bench timing only, no checks)

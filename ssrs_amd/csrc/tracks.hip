@@ -2890,8 +2890,13 @@ __global__ __launch_bounds__(BT) void k_step_roam(const StepArgs a, const ThrPri
         ++n_pairs;
         if (__builtin_expect(rare != 0ull, 0)) {
             if (__any(out)) {
+#ifdef SSRS_PROBE_NO_STRAY_ATOMICS      // timing probe (wrong histogram): what the strays' global atomics cost a pass
+                if (go && !in_a) ++win_stray;
+                if (go && !in_b) ++win_stray;
+#else
                 if (go && !in_a) { atomicAdd(&a.hist[cell_a], 1u); ++win_stray; }
                 if (go && !in_b) { atomicAdd(&a.hist[cell_b], 1u); ++win_stray; }
+#endif
             }
             if (__any(slow)) {
                 ++n_slow;
@@ -3963,7 +3968,7 @@ extern "C" int ssrs_build_flags(void)
 {
 #if defined(SSRS_PROBE_NO_PHILOX) || defined(SSRS_PROBE_NO_GATHER) || defined(SSRS_PROBE_K2A_NOLOAD) || \
     defined(SSRS_PROBE_K2A_NOSTORE) || defined(SSRS_PROBE_K2A_PAD) || defined(SSRS_K2A_NT) || \
-    defined(SSRS_PROBE_K3_NOREAD) || defined(SSRS_PROBE_K3_NOFLUSH)
+    defined(SSRS_PROBE_K3_NOREAD) || defined(SSRS_PROBE_K3_NOFLUSH) || defined(SSRS_PROBE_NO_STRAY_ATOMICS)
     return 1;
 #else
     return 0;
