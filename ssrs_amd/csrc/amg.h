@@ -25,6 +25,11 @@ struct AmgLevel {
     int *rowptr = nullptr, *col = nullptr;
     double *val = nullptr, *dinv = nullptr;
     float *val32 = nullptr;    // the same entries rounded to f32 for the cycle's sweeps (levels >= 1)
+    // the same entries once more in sliced ELL form (slices of 64 rows, entry k of row 64 s + l at sell_ptr[s] + 64 k + l,
+    // short rows padded with (own column, 0)): a wave reads 64 consecutive entries per load and its 64 gathers of x go to
+    // neighbouring rows' neighbours -- the large levels' sweeps (amg.hip: k_sweep_sell; SSRS_AMG_NO_SELL: the CSR kernels)
+    int *sell_ptr = nullptr, *sell_col = nullptr;
+    float *sell_val = nullptr;
     int *agg = nullptr;        // fine node -> coarse node (-1: isolated row), NULL on the last level
     int *memptr = nullptr;     // coarse node I -> its fine nodes memidx[memptr[I] .. memptr[I+1])
     int *memidx = nullptr;

@@ -58,6 +58,9 @@ struct Bump {
     }
 };
 
+constexpr int kVectorRows = 1 << 17;     // levels at least this large use four lanes per row (CSR sweeps)
+constexpr int kSellRows = 1 << 17;       // ... and get a sliced ELL copy for the cycle's sweeps
+
 inline int grid_for(size_t n)
 {
     size_t b = (n + kBlock - 1) / kBlock;
@@ -520,6 +523,65 @@ __global__ __launch_bounds__(kBlock) void k_residual4(const int *__restrict__ ro
 #pragma unroll
         for (int u = 0; u < kRowsPerGroup; ++u)
             if (sub == 0 && row[u] < n) r[row[u]] = static_cast<cv_t>(b[row[u]] - ax[u]);
+    }
+}
+
+// ---- sliced ELL form of a level's f32 entries (AmgLevel::sell_*) and its sweeps
+__global__ __launch_bounds__(kBlock) void k_sell_widths(const int *__restrict__ rowptr, int n, int nsl, int *__restrict__ cnt)
+{
+    const int lane = threadIdx.x & 63;
+    for (int s = blockIdx.x * (kBlock / 64) + static_cast<int>(threadIdx.x >> 6); s < nsl; s += gridDim.x * (kBlock / 64)) {
+        const int row = s * 64 + lane;
+        int len = row < n ? rowptr[row + 1] - rowptr[row] : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(len, off); len = o > len ? o : len; }
+        if (lane == 0) cnt[s] = len * 64;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt[nsl] = 0;
+}
+
+__global__ __launch_bounds__(kBlock) void k_sell_fill(const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                     const float *__restrict__ val, int n, int nsl,
+                                                     const int *__restrict__ sell_ptr, int *__restrict__ sell_col,
+                                                     float *__restrict__ sell_val)
+{
+    const int lane = threadIdx.x & 63;
+    for (int s = blockIdx.x * (kBlock / 64) + static_cast<int>(threadIdx.x >> 6); s < nsl; s += gridDim.x * (kBlock / 64)) {
+        const int row = s * 64 + lane;
+        const int p0 = sell_ptr[s], width = (sell_ptr[s + 1] - p0) / 64;
+        const int r0 = row < n ? rowptr[row] : 0, len = row < n ? rowptr[row + 1] - r0 : 0;
+        for (int k = 0; k < width; ++k) {
+            const bool has = k < len;
+            sell_col[p0 + 64 * k + lane] = has ? col[r0 + k] : (row < n ? row : 0);
+            sell_val[p0 + 64 * k + lane] = has ? val[r0 + k] : 0.0f;
+        }
+    }
+}
+
+// JAC: xn = x + w D^-1 (b - A x); else r = b - A x.  One wave = one slice; four entries per lane in flight
+template <bool JAC>
+__global__ __launch_bounds__(kBlock) void k_sweep_sell(const int *__restrict__ sell_ptr, const int *__restrict__ sell_col,
+                                                      const float *__restrict__ sell_val, const cv_t *__restrict__ dinv,
+                                                      const cv_t *__restrict__ b, const cv_t *__restrict__ x, int n, int nsl,
+                                                      cv_t *__restrict__ out, double w)
+{
+    const int lane = threadIdx.x & 63;
+    for (int s = blockIdx.x * (kBlock / 64) + static_cast<int>(threadIdx.x >> 6); s < nsl; s += gridDim.x * (kBlock / 64)) {
+        const int p1 = sell_ptr[s + 1];
+        int p = sell_ptr[s] + lane;
+        double ax = 0.0;
+        for (; p + 3 * 64 < p1; p += 4 * 64) {
+            const int c0 = sell_col[p], c1 = sell_col[p + 64], c2 = sell_col[p + 128], c3 = sell_col[p + 192];
+            const float v0 = sell_val[p], v1 = sell_val[p + 64], v2 = sell_val[p + 128], v3 = sell_val[p + 192];
+            const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+            ax += static_cast<double>(v0) * x0;
+            ax += static_cast<double>(v1) * x1;
+            ax += static_cast<double>(v2) * x2;
+            ax += static_cast<double>(v3) * x3;
+        }
+        for (; p < p1; p += 64) ax += static_cast<double>(sell_val[p]) * x[sell_col[p]];
+        const int row = s * 64 + lane;
+        if (row < n) out[row] = static_cast<cv_t>(JAC ? x[row] + w * dinv[row] * (b[row] - ax) : b[row] - ax);
     }
 }
 
@@ -1257,6 +1319,29 @@ int amg_setup(AmgHierarchy &h, const double *cond, const uint8_t *fixed, int row
         }
         SSRS_HIP_CHECK(hipGetLastError());
     }
+    // ---- sliced ELL copies of the large levels (the ones whose sweeps ran four lanes per row)
+    if (!std::getenv("SSRS_AMG_NO_SELL")) {
+        for (size_t lev = 1; lev < h.levels.size(); ++lev) {
+            AmgLevel &Lv = h.levels[lev];
+            if (Lv.n < kSellRows || !Lv.val32) continue;
+            const int nsl = (Lv.n + 63) / 64;
+            int *cnt;
+            AMG_TAKE(cnt, int, nsl + 1);
+            AMG_TAKE(Lv.sell_ptr, int, nsl + 1);
+            hipLaunchKernelGGL(k_sell_widths, dim3(grid_for(static_cast<size_t>(nsl) * 64)), dim3(kBlock), 0, st, Lv.rowptr, Lv.n, nsl, cnt);
+            size_t tb = cub_tb;
+            SSRS_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, tb, cnt, Lv.sell_ptr, nsl + 1, st));
+            int total = 0;
+            SSRS_HIP_CHECK(hipMemcpyAsync(&total, Lv.sell_ptr + nsl, sizeof(int), hipMemcpyDeviceToHost, st));
+            SSRS_HIP_CHECK(hipStreamSynchronize(st));
+            if (total <= 0 || static_cast<size_t>(total) > 2 * static_cast<size_t>(Lv.nnz) + 64u * 64u) { Lv.sell_ptr = nullptr; continue; }   // (padding would double it: CSR)
+            AMG_TAKE(Lv.sell_col, int, total);
+            AMG_TAKE(Lv.sell_val, float, total);
+            hipLaunchKernelGGL(k_sell_fill, dim3(grid_for(static_cast<size_t>(nsl) * 64)), dim3(kBlock), 0, st, Lv.rowptr, Lv.col, Lv.val32, Lv.n, nsl,
+                               Lv.sell_ptr, Lv.sell_col, Lv.sell_val);
+        }
+        SSRS_HIP_CHECK(hipGetLastError());
+    }
 
     // ---- dense inverse of the coarsest level when it is small enough
     AmgLevel &B = h.levels.back();
@@ -1282,7 +1367,13 @@ int amg_setup(AmgHierarchy &h, const double *cond, const uint8_t *fixed, int row
 
 static void solve_level(AmgHierarchy &h, size_t lev, hipStream_t st);
 
-constexpr int kVectorRows = 1 << 17;     // levels at least this large use four lanes per row
+
+// one wave per slice of 64 rows, at most 16 384 blocks (the kernels stride)
+static dim3 sell_grid(int n)
+{
+    const size_t blocks = (static_cast<size_t>((n + 63) / 64) + kBlock / 64 - 1) / (kBlock / 64);
+    return dim3(static_cast<unsigned>(blocks < 1 ? 1 : (blocks > 16384 ? 16384 : blocks)));
+}
 
 // level-0 stencil kernels: blockIdx.y = row, a block = 4 waves x 62 cells of it
 static dim3 l0_grid(const AmgHierarchy &h)
@@ -1299,7 +1390,10 @@ static void launch_jacobi(AmgHierarchy &h, size_t lev, const cv_t *x, cv_t *xn, 
         hipLaunchKernelGGL(k_l0_jacobi, l0_grid(h), dim3(kBlock), 0, st, a, L.dinvc, L.b, x, xn, static_cast<cv_t>(w));
     } else {
         const dim3 g4(grid_for((static_cast<size_t>(L.n) + kRowsPerGroup - 1) / kRowsPerGroup * kRowLanes)), g1(grid_for(L.n));
-        if (L.n >= kVectorRows && L.val32)
+        if (L.sell_ptr && L.sell_val)
+            hipLaunchKernelGGL(k_sweep_sell<true>, sell_grid(L.n), dim3(kBlock), 0, st, L.sell_ptr, L.sell_col, L.sell_val, L.dinvc, L.b, x, L.n,
+                               (L.n + 63) / 64, xn, w);
+        else if (L.n >= kVectorRows && L.val32)
             hipLaunchKernelGGL(k_jacobi4<float>, g4, dim3(kBlock), 0, st, L.rowptr, L.col, L.val32, L.dinvc, L.b, x, L.n, xn, w);
         else if (L.n >= kVectorRows)
             hipLaunchKernelGGL(k_jacobi4<double>, g4, dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.dinvc, L.b, x, L.n, xn, w);
@@ -1319,7 +1413,10 @@ static void launch_residual(AmgHierarchy &h, size_t lev, hipStream_t st, const c
         hipLaunchKernelGGL(k_l0_residual, l0_grid(h), dim3(kBlock), 0, st, a, L.b, x, L.r);
     } else {
         const dim3 g4(grid_for((static_cast<size_t>(L.n) + kRowsPerGroup - 1) / kRowsPerGroup * kRowLanes)), g1(grid_for(L.n));
-        if (L.n >= kVectorRows && L.val32)
+        if (L.sell_ptr && L.sell_val)
+            hipLaunchKernelGGL(k_sweep_sell<false>, sell_grid(L.n), dim3(kBlock), 0, st, L.sell_ptr, L.sell_col, L.sell_val, L.dinvc, L.b, x, L.n,
+                               (L.n + 63) / 64, L.r, 0.0);
+        else if (L.n >= kVectorRows && L.val32)
             hipLaunchKernelGGL(k_residual4<float>, g4, dim3(kBlock), 0, st, L.rowptr, L.col, L.val32, L.b, x, L.n, L.r);
         else if (L.n >= kVectorRows)
             hipLaunchKernelGGL(k_residual4<double>, g4, dim3(kBlock), 0, st, L.rowptr, L.col, L.val, L.b, x, L.n, L.r);

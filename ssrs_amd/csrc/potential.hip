@@ -798,7 +798,14 @@ extern "C" int ssrs_potential_solve(const double *conductivity, const uint8_t *f
         else if (use_amg && !robust_cycle && it - gain_it >= 40) {
             robust_cycle = true;
             robust_from = it;
+            gain_it = it;
             if (progress) fprintf(stderr, "[ssrs_potential_solve] BiCGStab it %d: no factor of two in 40 iterations (|r|/|b| %.3e): V(2,2) from here on\n", it, now);
+        } else if (use_amg && robust_cycle && pcg_ok && it - gain_it >= 60 && std::getenv("SSRS_SOLVE_NO_FALLBACK") == nullptr) {
+            // stagnation under the robust cycle too (snapshot 25 of configs[4] with the sliced-ELL sweeps' rounding: the
+            // residual sat at 5.9e-11 from iteration 200 to the cap at 1 695): no point in waiting for the cap -- the
+            // fall-back below takes ~400 PCG iterations from where PCG stood
+            if (progress) fprintf(stderr, "[ssrs_potential_solve] BiCGStab it %d: no factor of two in 60 iterations under V(2,2) either (|r|/|b| %.3e)\n", it, now);
+            break;
         }
         // BiCGStab breakdown (rho or omega -> 0) or a residual that ran away:
         // restart from the best iterate with a fresh shadow residual
