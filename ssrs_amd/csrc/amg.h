@@ -66,6 +66,7 @@ struct AmgHierarchy {
     // so that the captured graph serves every (rhs, out) pair.  A/B: SSRS_AMG_NO_FUSE
     void *l0_slots = nullptr;
     bool fuse0 = false;
+    bool l0_blocks = false;        // level 1 = parts of aligned 2 x 2 raster blocks (k_block_agg): the two-row level-0 kernels restrict in place
     const uint8_t *l0_fixed = nullptr;
     int l0_rows = 0, l0_cols = 0;
 };

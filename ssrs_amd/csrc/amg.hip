@@ -792,6 +792,140 @@ __global__ __launch_bounds__(kBlock) void k_l0_post_fused(const double *__restri
     }
 }
 
+// ---- the same two passes for TWO raster rows per wave (round 4, late): a wave that computes rows 2R and 2R + 1 loads rows
+// 2R - 1 .. 2R + 2 once -- 12 loads for two rows of the pre pass instead of 18, 20 instead of 28 in the post pass (the
+// kernels are bound by their load instructions) -- and, since level 1's aggregates are the parts of the aligned 2 x 2 blocks
+// (k_block_agg), the pre pass has every member of an aggregate in two neighbouring lanes: it writes the restricted residual
+// itself (members added in index order, as k_restrict does) instead of writing r for k_restrict to gather.  Same arithmetic
+// per cell in the same order as l0_core: bit-identical to the one-row kernels (SSRS_AMG_L0_ONE_ROW) and to the unfused path.
+__device__ __forceinline__ void l0_shift4(const double (&v)[4], double (&l)[4], double (&r)[4])
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { l[k] = __shfl_up(v[k], 1); r[k] = __shfl_down(v[k], 1); }
+}
+
+// row d0 + 1 of the four loaded rows (d0 = 0: row 2R, d0 = 1: row 2R + 1); l / c / r = west / own / east columns
+__device__ __forceinline__ double l0_core4(const double (&xl)[4], const double (&xc)[4], const double (&xr)[4],
+                                           const double (&sl)[4], const double (&sc)[4], const double (&sr)[4], int d0)
+{
+    const double inf = __builtin_inf();
+    const double si = sc[d0 + 1], ri = fabs(si);
+    double diag = 0.0, off = 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        if (k == 4) continue;
+        const int d = k / 3, dc = k % 3 - 1;
+        const double sj = dc < 0 ? sl[d0 + d] : (dc > 0 ? sr[d0 + d] : sc[d0 + d]);
+        const double xj = dc < 0 ? xl[d0 + d] : (dc > 0 ? xr[d0 + d] : xc[d0 + d]);
+        const double rj = fabs(sj);
+        double w = (ri != 0.0 && rj != 0.0) ? 2.0 / (ri + rj) : 1e-08;
+        if (rj == inf) w = 0.0;
+        if (d != 1 && dc != 0) w = w * kInvFacDiag;
+        diag += w;
+        if (!signbit(sj)) off += w * xj;
+    }
+    if (signbit(si)) return xc[d0 + 1];                       // Dirichlet cell: identity row
+    return diag * xc[d0 + 1] - off;
+}
+
+// pre: x = w D^-1 b, r = b - A x; bc = R r when `agg` is given (r is then not written at all), else r is written
+__global__ __launch_bounds__(kBlock) void k_l0_pre2(const double *__restrict__ rinv, int rows, int cols,
+                                                   const double *__restrict__ dinv, const L0Slots *__restrict__ slots,
+                                                   double w, double *__restrict__ x, double *__restrict__ r,
+                                                   const int *__restrict__ agg, double *__restrict__ bc)
+{
+    const double *__restrict__ b = slots->rhs;
+    const int c = (static_cast<int>(blockIdx.x) * (kBlock / 64) + static_cast<int>(threadIdx.x >> 6)) * kL0Cols +
+                  static_cast<int>(threadIdx.x & 63) - 1;
+    const int row0 = 2 * static_cast<int>(blockIdx.y), lane = threadIdx.x & 63;
+    const bool col_ok = c >= 0 && c < cols;
+    double xv[4], sv[4], bv[2] = {0.0, 0.0};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int rr = row0 + d - 1;
+        const bool ok = col_ok && rr >= 0 && rr < rows;
+        const size_t j = static_cast<size_t>(ok ? rr : row0) * cols + (col_ok ? c : 0);
+        const double bj = ok ? b[j] : 0.0;
+        xv[d] = ok ? w * dinv[j] * bj : 0.0;
+        sv[d] = ok ? rinv[j] : __builtin_inf();
+        if (d == 1) bv[0] = bj;
+        if (d == 2) bv[1] = bj;
+    }
+    double xl[4], xr[4], sl[4], sr[4];
+    l0_shift4(xv, xl, xr);
+    l0_shift4(sv, sl, sr);
+    const double ax0 = l0_core4(xl, xv, xr, sl, sv, sr, 0), ax1 = l0_core4(xl, xv, xr, sl, sv, sr, 1);
+    const bool centre = col_ok && lane >= 1 && lane <= kL0Cols, row1_ok = row0 + 1 < rows;
+    const size_t i0 = static_cast<size_t>(row0) * cols + (col_ok ? c : 0), i1 = i0 + cols;
+    const double r0 = bv[0] - ax0, r1 = bv[1] - ax1;
+    if (centre) {
+        x[i0] = xv[1];
+        if (row1_ok) x[i1] = xv[2];
+        if (!agg) {
+            r[i0] = r0;
+            if (row1_ok) r[i1] = r1;
+        }
+    }
+    if (agg) {
+        // the 2 x 2 block = lanes (l, l + 1) with l odd (c even; a wave's first column is even) x rows (2R, 2R + 1)
+        const int a0 = centre ? agg[i0] : -1, a1 = (centre && row1_ok) ? agg[i1] : -1;
+        const double q0 = __shfl_down(r0, 1), q1 = __shfl_down(r1, 1);
+        const int e0 = __shfl_down(a0, 1), e1 = __shfl_down(a1, 1);
+        if ((lane & 1) && centre) {
+            const bool east = lane + 1 <= kL0Cols;                  // (lane 63 is the halo: a wave's 62 columns are 31 whole blocks)
+            const int am[4] = {a0, east ? e0 : -1, a1, east ? e1 : -1};
+            const double rm[4] = {r0, q0, r1, q1};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (am[i] < 0) continue;
+                bool first = true;
+#pragma unroll
+                for (int j = 0; j < i; ++j) first = first && am[j] != am[i];
+                if (!first) continue;
+                double s = 0.0;
+                s += rm[i];
+#pragma unroll
+                for (int j = i + 1; j < 4; ++j)
+                    if (am[j] == am[i]) s += rm[j];
+                bc[am[i]] = s;
+            }
+        }
+    }
+}
+
+// post: x' = x + P x_c and out = x' + w D^-1 (b - A x'), two rows per wave
+__global__ __launch_bounds__(kBlock) void k_l0_post2(const double *__restrict__ rinv, int rows, int cols,
+                                                    const double *__restrict__ dinv, const L0Slots *__restrict__ slots,
+                                                    const int *__restrict__ agg, const double *__restrict__ xc,
+                                                    const double *__restrict__ x, double w)
+{
+    const double *__restrict__ b = slots->rhs;
+    double *__restrict__ out = slots->out;
+    const int c = (static_cast<int>(blockIdx.x) * (kBlock / 64) + static_cast<int>(threadIdx.x >> 6)) * kL0Cols +
+                  static_cast<int>(threadIdx.x & 63) - 1;
+    const int row0 = 2 * static_cast<int>(blockIdx.y), lane = threadIdx.x & 63;
+    const bool col_ok = c >= 0 && c < cols;
+    double xv[4], sv[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int rr = row0 + d - 1;
+        const bool ok = col_ok && rr >= 0 && rr < rows;
+        const size_t j = static_cast<size_t>(ok ? rr : row0) * cols + (col_ok ? c : 0);
+        const int a = ok ? agg[j] : -1;
+        xv[d] = ok ? x[j] + (a >= 0 ? xc[a] : 0.0) : 0.0;
+        sv[d] = ok ? rinv[j] : __builtin_inf();
+    }
+    double xl[4], xr[4], sl[4], sr[4];
+    l0_shift4(xv, xl, xr);
+    l0_shift4(sv, sl, sr);
+    const double ax0 = l0_core4(xl, xv, xr, sl, sv, sr, 0), ax1 = l0_core4(xl, xv, xr, sl, sv, sr, 1);
+    if (col_ok && lane >= 1 && lane <= kL0Cols) {
+        const size_t i0 = static_cast<size_t>(row0) * cols + c, i1 = i0 + cols;
+        out[i0] = xv[1] + w * dinv[i0] * (b[i0] - ax0);
+        if (row0 + 1 < rows) out[i1] = xv[2] + w * dinv[i1] * (b[i1] - ax1);
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_l0_jacobi(L0Stencil a, const cv_t *__restrict__ dinv,
                                                      const cv_t *__restrict__ b,
                                                      const cv_t *__restrict__ x,
@@ -1122,6 +1256,7 @@ int amg_setup(AmgHierarchy &h, const double *cond, const uint8_t *fixed, int row
 {
     h.levels.clear();
     h.dense_inv = nullptr;
+    h.l0_blocks = false;
     Bump bump{static_cast<char *>(workspace), workspace_bytes, 0};
     const int n0 = rows * cols;
 
@@ -1225,6 +1360,7 @@ int amg_setup(AmgHierarchy &h, const double *cond, const uint8_t *fixed, int row
                 const long long nb = static_cast<long long>((rows + 1) / 2) * ((cols + 1) / 2);
                 hipLaunchKernelGGL(k_block_agg, dim3(grid_for(static_cast<size_t>(nb))), dim3(kBlock), 0, st, L.rowptr, L.col, L.val,
                                    L.dinv, rows, cols, match, joined, flag);
+                h.l0_blocks = true;
                 SSRS_HIP_CHECK(hipMemsetAsync(flag + n, 0, sizeof(int), st));
                 size_t tb = cub_tb;
                 SSRS_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, tb, flag, cid, n + 1, st));
@@ -1456,6 +1592,19 @@ static void cycle(AmgHierarchy &h, size_t lev, hipStream_t st)
             const double *rinv = reinterpret_cast<const double *>(h.l0_rinvc);
             const L0Slots *slots = static_cast<const L0Slots *>(h.l0_slots);
             AmgLevel &C1 = h.levels[1];
+            if (!std::getenv("SSRS_AMG_L0_ONE_ROW")) {
+                dim3 g2 = l0_grid(h);
+                g2.y = (g2.y + 1) / 2;
+                const bool in_place = h.l0_blocks && (kL0Cols % 2) == 0;       // restriction inside the pre pass
+                hipLaunchKernelGGL(k_l0_pre2, g2, dim3(kBlock), 0, st, rinv, h.l0_rows, h.l0_cols, reinterpret_cast<const double *>(L.dinvc),
+                                   slots, h.om[0], reinterpret_cast<double *>(L.xt), reinterpret_cast<double *>(L.r),
+                                   in_place ? L.agg : static_cast<const int *>(nullptr), reinterpret_cast<double *>(C1.b));
+                if (!in_place) hipLaunchKernelGGL(k_restrict, dim3(grid_for(C1.n)), dim3(kBlock), 0, st, L.memptr, L.memidx, L.r, C1.n, C1.b);
+                solve_level(h, 1, st);
+                hipLaunchKernelGGL(k_l0_post2, g2, dim3(kBlock), 0, st, rinv, h.l0_rows, h.l0_cols, reinterpret_cast<const double *>(L.dinvc),
+                                   slots, L.agg, reinterpret_cast<const double *>(C1.x), reinterpret_cast<const double *>(L.xt), h.om[0]);
+                return;
+            }
             hipLaunchKernelGGL(k_l0_pre_fused, l0_grid(h), dim3(kBlock), 0, st, rinv, h.l0_rows, h.l0_cols,
                                reinterpret_cast<const double *>(L.dinvc), slots, h.om[0], reinterpret_cast<double *>(L.xt),
                                reinterpret_cast<double *>(L.r));

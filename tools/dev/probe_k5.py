@@ -21,6 +21,7 @@ variants = [
     ('nu 1,1', {'SSRS_AMG_NU': '1,1'}, {}),
     ('nu 2,1', {'SSRS_AMG_NU': '2,1'}, {}),
     ('no sell', {'SSRS_AMG_NO_SELL': '1'}, {}),
+    ('one row', {'SSRS_AMG_L0_ONE_ROW': '1'}, {}),
     ('ramp guess', {}, {'initial_guess': ramp}),
     ('nu 1,1 + ramp', {'SSRS_AMG_NU': '1,1'}, {'initial_guess': ramp}),
 ]
