@@ -303,20 +303,24 @@ class Passes:
         safe = max(1, -(-n // nsub))
         outs = []
         hist64 = None
-        # more tracks than a uint32 histogram is safe for (trap cells of the solved field collect ~1e4 visits per
-        # track): sub-batches added up in 64 bits, as ssrs_amd.Simulator does (Config.hist_safe_tracks)
+        # a sub-batch of more than ~240 000 tracks takes the trap cells of the solved field past 2^32 visits (1.7e4 per track):
+        # sub-batches larger than 100 000 tracks count in 64 bits inside the library (ssrs_tracks_simulate_h64: the kernels'
+        # uint32 raster is emptied into the 64-bit one every other batch), as ssrs_amd.Simulator does; smaller ones count
+        # into the uint32 raster and are added up in 64 bits here when there are several (Config.hist_safe_tracks)
+        in_lib = safe > 100_000 and not args.direct
         for b0 in range(0, n, safe):
-            if n > safe:
+            if n > safe or in_lib:
                 if hist64 is None:
                     hist64 = torch.zeros(self.gridsize, dtype=torch.int64, device=hist.device)
-                hist.zero_()
+                if not in_lib:
+                    hist.zero_()
             o = self.movmodel.simulate_tracks(0.0, self.starts[b0:b0 + safe], self.gridsize, 1, 1.0, upd, self.pot, seed=self.seed,
                                               track_id_base=self.lo + b0, table=table, use_table=not args.direct,
-                                              hist=hist, steps_per_launch=args.steps_per_launch,
+                                              hist=hist64 if in_lib else hist, hist64=in_lib, steps_per_launch=args.steps_per_launch,
                                               profile=True, exact_only=args.exact_only,
                                               schedule=not args.no_schedule, binning=not args.no_binning)
             outs.append(o)
-            if hist64 is not None:
+            if hist64 is not None and not in_lib:
                 hist64 += hist.to(torch.int64) & 0xFFFFFFFF
         out = outs[0] if len(outs) == 1 else _MergedPass(outs)
         # (widens to 64 bits by itself when the ranks' largest counts could wrap a 32-bit sum)

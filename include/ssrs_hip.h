@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SSRS_VERSION 107 /* 0.1.7 */
+#define SSRS_VERSION 108 /* 0.1.8 */
 
 #define SSRS_OK 0
 #define SSRS_ERR_INVALID (-1) /* bad argument (message says which) */
@@ -324,6 +324,18 @@ int ssrs_tracks_simulate(const SsrsTrackParams *params, const double *updraft,
                          const int64_t *traj_offsets, void *workspace,
                          size_t workspace_bytes, SsrsTrackStats *stats,
                          void *stream);
+
+/* ssrs_tracks_simulate (no trajectories) with the presence counts in 64 bits: compute_presence_counts' int16 raster
+ * (movmodel.py:415) wraps at 32 767 visits and this library's uint32 one at 2^32 - 1, which the trap cells of a solved 10 m
+ * field reach from ~250 000 tracks of one call on (1.7e4 visits per track).  The kernels count into `hist_scratch`
+ * (uint32 (rows, cols), zeroed by the caller: whatever it holds is counted too) and the library empties it into `hist64`
+ * (uint64 (rows, cols), ACCUMULATED) every other batch of launches and before it returns, on `stream`. */
+int ssrs_tracks_simulate_h64(const SsrsTrackParams *params, const double *updraft,
+                             const float *potential, const double *table,
+                             const int32_t *start_rc, int64_t ntracks, uint64_t seed,
+                             uint64_t track_id_base, uint32_t *hist_scratch, uint64_t *hist64,
+                             int16_t *end_rc, int32_t *lengths, void *workspace,
+                             size_t workspace_bytes, SsrsTrackStats *stats, void *stream);
 
 /* Trajectory output in ONE simulation pass (the List[int16 (n_i, 2)] that
  * Simulator.simulate_tracks pickles, simulator.py:360-385).  The two-call form above needs

@@ -32,7 +32,7 @@ EXPORTS = (
     'ssrs_transition_thr_bytes', 'ssrs_transition_thr_build',
     'ssrs_tracks_workspace_bytes', 'ssrs_tracks_workspace_bytes_ex', 'ssrs_tracks_simulate', 'ssrs_uniform_selftest',
     'ssrs_traj_recorder_create', 'ssrs_traj_recorder_destroy', 'ssrs_traj_recorder_complete',
-    'ssrs_traj_recorder_used', 'ssrs_tracks_simulate_rec', 'ssrs_tracks_gather',
+    'ssrs_traj_recorder_used', 'ssrs_tracks_simulate_rec', 'ssrs_tracks_gather', 'ssrs_tracks_simulate_h64',
     'ssrs_hist_reduce', 'ssrs_presence_count', 'ssrs_presence_workspace_bytes', 'ssrs_presence_smooth',
     'ssrs_presence_smooth_u64',
     'ssrs_presence_normalise_add', 'ssrs_presence_normalise_f32',

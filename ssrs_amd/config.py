@@ -96,9 +96,11 @@ class Config:
     steps_per_launch: int = 0           # 0 = library default
     max_tracks_file_gb: float = 64.     # refuse a <id>_tracks.pkl larger than this (tracks that wander to
     #                                     max_moves: 1 TB per 100k tracks on a solved 10 m field)
-    hist_safe_tracks: int = 250_000     # tracks per sub-batch of a case: (i) a uint32 presence histogram is safe for this many on
-    #                                     the solved 10 m field (a trap cell takes ~1e4 visits per track; more are added up in 64
-    #                                     bits, and a sub-batch whose counts wrap all the same is stepped again as two halves);
+    hist_safe_tracks: int = 250_000     # tracks per sub-batch of a case: (i) histograms of several sub-batches are added up in 64
+    #                                     bits; a sub-batch of more than 100 000 tracks is counted in 64 bits inside the library (a trap
+    #                                     cell of the solved 10 m field takes 1.7e4 visits per track: 2^32 from ~245 000 tracks on;
+    #                                     ssrs_tracks_simulate_h64), and a smaller one whose uint32 counts wrap all the same -- or one
+    #                                     with trajectories, which stay on the uint32 raster -- is stepped again as two halves;
     #                                     (ii) ~42 % of such a batch ends up roaming, and the roaming stepper holds ONE block per
     #                                     CU: 250 000 tracks = ~105 000 roaming at first, one round of 512-lane blocks, later
     #                                     ~78 000 in 256-lane blocks: 2.0 s per pass = 1.27e5 tracks/s against 1.0e5 for 140 000

@@ -3238,6 +3238,16 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_visits16(const uint16_t *__
 // in the caller's workspace when it is large enough, ssrs_tracks_workspace_bytes_ex);
 // the copies are added to `hist` once at the end.  5.8 -> 14 (K = 16) / 17.5 (K = 64)
 // G steps/s on the C2 run.
+// hist64 += hist32, hist32 = 0 (ssrs_tracks_simulate_h64: a roaming batch's trap cells pass 2^32 visits from ~250 000 tracks
+// on: the 32-bit raster the kernels count into is emptied into the caller's 64-bit one every other batch and at the end)
+__global__ __launch_bounds__(kBlock) void k_drain64(uint32_t *__restrict__ lo, unsigned long long *__restrict__ acc, size_t n)
+{
+    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * kBlock) {
+        const uint32_t v = lo[i];
+        if (v) { acc[i] += v; lo[i] = 0u; }
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_fold_copies(const uint32_t *__restrict__ copies, int ncopies,
                                                        size_t ncell, uint32_t *__restrict__ hist)
 {
@@ -4136,9 +4146,11 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
                                 uint64_t track_id_base, uint32_t *hist, int16_t *end_rc,
                                 int32_t *lengths, int16_t *traj, const int64_t *traj_offsets,
                                 void *workspace, size_t workspace_bytes,
-                                SsrsTrackStats *stats, void *stream, SsrsTrajRecorder *rec)
+                                SsrsTrackStats *stats, void *stream, SsrsTrajRecorder *rec,
+                                unsigned long long *hist64 = nullptr)
 {
     SSRS_REQUIRE(p != nullptr, "ssrs_tracks_simulate: params is NULL");
+    SSRS_REQUIRE(hist64 == nullptr || hist != nullptr, "ssrs_tracks_simulate_h64: the 32-bit raster the kernels count into is NULL");
     SSRS_REQUIRE(p->rows >= 5 && p->cols >= 5, "ssrs_tracks_simulate: need rows, cols >= 5 (got %d x %d)",
                  p->rows, p->cols);
     SSRS_REQUIRE(p->rows <= 32767 && p->cols <= 32767,
@@ -4784,6 +4796,10 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
             if (hipGetLastError() != hipSuccess) { rc = set_error(SSRS_ERR_HIP, "stepper launch failed"); break; }
         }
         if (rc != SSRS_OK) break;
+        if (hist64 && cached && (batches & 1)) {          // (block windows flush whole launches' counts at once)
+            hipLaunchKernelGGL(k_drain64, dim3(4096), dim3(kBlock), 0, st, hist, hist64, ncell);
+            marks_adjacent = false;
+        }
         // survivors of this batch = input count of the next launch
         // ring slot = the head of the control block in one copy: [4][8] list counts, error, par_min,
         // steps (2 words), strays (2 words); the row this batch's survivors went to is count[launch & 3]
@@ -4905,6 +4921,7 @@ static int tracks_simulate_impl(const SsrsTrackParams *p, const double *updraft,
     if (hist_t && rc == SSRS_OK)
         hipLaunchKernelGGL(k_transpose_add, dim3(static_cast<unsigned>(((p->rows + 31) / 32) * ((p->cols + 31) / 32))),
                            dim3(kBlock), 0, st, hist_t, p->rows, p->cols, hist);
+    if (hist64 && rc == SSRS_OK) hipLaunchKernelGGL(k_drain64, dim3(4096), dim3(kBlock), 0, st, hist, hist64, ncell);
     (void)hipEventRecord(ev_last, st);
     // fetch step total + error flag
     TrackCtl host_ctl = {};
@@ -4993,6 +5010,20 @@ extern "C" int ssrs_tracks_simulate(const SsrsTrackParams *p, const double *updr
 {
     return tracks_simulate_impl(p, updraft, potential, table, start_rc, ntracks, seed, track_id_base, hist, end_rc,
                                 lengths, traj, traj_offsets, workspace, workspace_bytes, stats, stream, nullptr);
+}
+
+extern "C" int ssrs_tracks_simulate_h64(const SsrsTrackParams *p, const double *updraft,
+                                        const float *potential, const double *table,
+                                        const int32_t *start_rc, int64_t ntracks, uint64_t seed,
+                                        uint64_t track_id_base, uint32_t *hist_scratch, uint64_t *hist64, int16_t *end_rc,
+                                        int32_t *lengths, void *workspace, size_t workspace_bytes,
+                                        SsrsTrackStats *stats, void *stream)
+{
+    SSRS_REQUIRE(hist_scratch != nullptr && hist64 != nullptr, "ssrs_tracks_simulate_h64: NULL histogram");
+    static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "64-bit counts");
+    return tracks_simulate_impl(p, updraft, potential, table, start_rc, ntracks, seed, track_id_base, hist_scratch, end_rc,
+                                lengths, nullptr, nullptr, workspace, workspace_bytes, stats, stream, nullptr,
+                                reinterpret_cast<unsigned long long *>(hist64));
 }
 
 extern "C" SsrsTrajRecorder *ssrs_traj_recorder_create(void *pool, size_t pool_bytes)

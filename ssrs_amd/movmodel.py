@@ -262,7 +262,7 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
                     seed=0, track_id_base=0, table=None, use_table=None, hist=None,
                     want_hist=True, want_tracks=False, steps_per_launch=0, profile=False,
                     exact_only=False, schedule=True, binning=True, ring=None, scattered=None,
-                    max_moves=None, record=True, record_pool_bytes=None, thr=None, traj_budget_bytes=None):
+                    max_moves=None, record=True, record_pool_bytes=None, thr=None, traj_budget_bytes=None, hist64=False):
     """generate_simulated_tracks for a whole batch (movmodel.py:264-318 under
     simulator.py:360-369) + presence histogram (movmodel.py:410-419).
 
@@ -275,7 +275,10 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
     table is built here, the threshold table (build_transition_table(..., thr=True)) is
     picked whenever it applies (memory 1, nu 1, rows * cols < 2^26); ring=True / thr=False
     ask for the ring table, ring=False for the f64 table.
-    `hist` (int32/uint32 CUDA tensor) is accumulated into when given.
+    `hist` (int32/uint32 CUDA tensor) is accumulated into when given.  hist64=True (no trajectories): the counts come back
+    as an int64 tensor -- the kernels count into a uint32 scratch raster that the library empties into it every other batch
+    (ssrs_tracks_simulate_h64): the trap cells of a solved 10 m field pass 2^32 visits from ~250 000 tracks of one call on;
+    `hist`, when given, must then be int64 and is accumulated into.
 
     want_tracks: trajectories (TrackBatch.tracks()).  record=True (default) keeps every
     launch's visited cells in a device pool and assembles the trajectories afterwards
@@ -327,6 +330,15 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
                           ring=is_ring and not is_thr, scattered=scattered, thr=is_thr)
     if max_moves is not None:          # probe hook: cap below the reference's R/2 * C/2 (movmodel.py:277)
         p.max_moves = int(max_moves)
+    hist_scratch = None
+    if hist64:
+        if want_tracks:
+            raise ValueError('hist64 goes with want_tracks=False')
+        if hist is None:
+            hist = torch.zeros((rows, cols), dtype=torch.int64, device=dev)
+        elif hist.dtype != torch.int64:
+            raise ValueError('hist64=True: `hist` must be an int64 tensor')
+        hist_scratch = torch.zeros((rows, cols), dtype=torch.int32, device=dev)
     if hist is None and want_hist:
         hist = torch.zeros((rows, cols), dtype=torch.int32, device=dev)
     lengths = torch.empty(n, dtype=torch.int32, device=dev)
@@ -430,6 +442,12 @@ def simulate_tracks(move_dirn, starts, grid_shape, memory_parameter=1,
                 if not torch.equal(sub_len, lengths[t0:t1]):
                     raise RuntimeError('trajectory replay: a track changed its length between the passes')
                 return out.cpu().numpy()
+    elif hist64:
+        nat.check(nat.lib().ssrs_tracks_simulate_h64(
+            C.byref(p), nat.ptr(upd), nat.ptr(pot), nat.ptr(table), nat.ptr(st),
+            C.c_int64(n), C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF),
+            C.c_uint64(int(track_id_base)), nat.ptr(hist_scratch), nat.ptr(hist), nat.ptr(ends),
+            nat.ptr(lengths), nat.ptr(ws), C.c_size_t(ws_bytes), C.byref(stats), stream_ptr()))
     elif not want_tracks:
         run(hist, None, None)
     return TrackBatch(lengths, ends, hist, traj, offsets, replay=replay, stats=

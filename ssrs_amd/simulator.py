@@ -557,6 +557,7 @@ class Simulator(Config):
                 collect(f.result() for f in pending)
 
     _MIN_SPLIT_TRACKS = 64          # a wrapped sub-batch smaller than twice this is an error, not a split
+    _HIST64_FROM_TRACKS = 100_000   # sub-batches larger than this count in 64 bits (when no trajectories are asked for)
 
     def _step_case(self, my_starts, lo, fields, seed, use_table, widest_share=None):
         """The tracks of one (case, realisation) on this rank.  The presence histogram is uint32 (the
@@ -579,12 +580,19 @@ class Simulator(Config):
         while todo:
             t0, m = todo.pop(0)
             sub = my_starts[t0:t0 + m]
+            # large sub-batches without trajectories count in 64 bits inside the library (the trap cells of a solved 10 m field
+            # pass 2^32 visits from ~250 000 tracks on: ssrs_tracks_simulate_h64); the others keep the uint32 raster
+            use64 = not self.save_tracks and m > self._HIST64_FROM_TRACKS
             b = movmodel.simulate_tracks(
                 self.track_direction, sub, self.gridsize, self.track_dirn_restrict,
                 self.track_stochastic_nu, fields[0], fields[1], seed=seed, track_id_base=lo + t0,
                 use_table=use_table, want_tracks=bool(self.save_tracks),
-                steps_per_launch=self.steps_per_launch)
-            counted = int((b.hist.view(torch.int32).to(torch.int64) & 0xFFFFFFFF).sum().item())
+                steps_per_launch=self.steps_per_launch, hist64=use64)
+            if b.hist.dtype == torch.int64:
+                widen = True
+                counted = int(b.hist.sum().item())
+            else:
+                counted = int((b.hist.view(torch.int32).to(torch.int64) & 0xFFFFFFFF).sum().item())
             if counted != b.total_points:
                 if m < 2 * self._MIN_SPLIT_TRACKS:
                     raise HistogramOverflow(
@@ -602,7 +610,7 @@ class Simulator(Config):
                 continue
             parts.append(b)
             if widen:
-                h64 = b.hist.view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+                h64 = b.hist if b.hist.dtype == torch.int64 else b.hist.view(torch.int32).to(torch.int64) & 0xFFFFFFFF
                 wide = h64 if wide is None else wide.add_(h64)
                 b.hist = None
             if stats is None:

@@ -99,5 +99,15 @@ def test_single_rank_histogram_guard_and_64_bit_sub_batches(gpu, tmp_path):
     assert int(hist.sum().item()) == steps + 80_000
     assert int(hist.max().item()) > 2 ** 32                  # the cell that wrapped in the single histogram
     assert torch.equal(hist, halves)
+    # the same batch in ONE call with the counts in 64 bits inside the library (ssrs_tracks_simulate_h64: what sub-batches of
+    # more than 100 000 tracks get; forced here): nothing wraps, nothing is split, the same counts
+    import warnings
+    lib64 = Simulator(replace(cfg, run_name='w3'), terrain=flat)
+    lib64._HIST64_FROM_TRACKS = 10_000
+    np.save(os.path.join(lib64.mode_data_dir, 's10d270_d0_t75_fluidflow_r0_potential.npy'), pot)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error', RuntimeWarning)
+        lib64.simulate_tracks()
+    assert torch.equal(lib64._presence_counts[('s10d270', 0)], halves)
     out = safe.compute_presence_map(radius=100.)
     assert out.dtype == np.float32 and float(out.max()) == 1.0 and np.isfinite(out).all()

@@ -28,7 +28,7 @@ def test_header_symbols_are_exported():
 def test_version_and_error_text():
     from ssrs_amd import _native
     lib = _native.lib()
-    assert lib.ssrs_version() == 107
+    assert lib.ssrs_version() == 108
     assert isinstance(lib.ssrs_last_error(), bytes)
 
 
