@@ -178,3 +178,32 @@ def test_config2_share_125k_tracks_on_the_solved_field(c2_field):
     assert np.array_equal(lengths[:m][done], ref['lengths'][done])
     assert np.array_equal(ends[:m][done], ref['ends'][done])
     assert np.all(lengths[:m][~done] - 1 >= CAP)
+
+
+def test_quarter_million_tracks_start_wide_and_finish_narrow(c2_field):
+    """One call of 250 000 tracks on K5's field at full size, as `Simulator` cuts its sub-batches (Config.hist_safe_tracks): more
+    tracks roam at first than one round of 256-lane blocks holds, so the deals make 512-lane blocks until ~63 000 are left and
+    256-lane blocks after (tracks.hip: roam_width, chosen from the live count k_wander_windows reads out).  Against the same
+    call with 256-lane blocks only (SSRS_TRACKS_ROAM_WIDE=0, two rounds of blocks): identical lengths, end cells and 64-bit
+    counts; the counts hold every point once, and a trap cell is past 2^32 - 1 or close to it (why the counts are 64-bit:
+    ssrs_tracks_simulate_h64)."""
+    import os
+    from ssrs_amd import movmodel
+    f = c2_field
+    n = 250_000
+    np.random.seed(30)
+    r, c = movmodel.get_starting_indices(n, (5, 55, 1, 2), 'random', (60., 50.), RES)
+    starts = np.stack([r, c], 1).astype(np.int32)
+    got = movmodel.simulate_tracks(0., starts, SHAPE, 1, 1., f['upd'], f['pot'], seed=30, hist64=True)
+    st = got.stats
+    assert 0 < st['roam_wide_launches'] < st['roam_launches'], st
+    assert got.hist.dtype == torch.int64
+    assert int(got.hist.sum().item()) == st['total_steps'] + n == int(got.lengths.sum(dtype=torch.int64).item())
+    assert int(got.hist.max().item()) > 3.5e9
+    os.environ['SSRS_TRACKS_ROAM_WIDE'] = '0'
+    try:
+        alt = movmodel.simulate_tracks(0., starts, SHAPE, 1, 1., f['upd'], f['pot'], seed=30, hist64=True)
+    finally:
+        del os.environ['SSRS_TRACKS_ROAM_WIDE']
+    assert alt.stats['roam_wide_launches'] == 0
+    assert torch.equal(alt.lengths, got.lengths) and torch.equal(alt.ends, got.ends) and torch.equal(alt.hist, got.hist)
