@@ -2,7 +2,7 @@
 # usage: prof_solved_pass.sh TAG ["extra bench.py args, e.g. --tracks 250000"] ["what the pass is, for the titles"]
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 TAG=${1:-r03_solved}
-CMD="python3 bench.py --steps 1 --warmup 0 --cpu-seconds 0 --stand-in-steps 0 --no-chain-probe $2"
+CMD="python3 bench.py --steps 1 --warmup 0 --cpu-seconds 0 --stand-in-steps 0 --no-chain-probe --full-chip-tracks 0 $2"
 WHAT=${3:-100k tracks through the K5 field, one pass incl. the solve; MI355X}
 rm -rf /tmp/psol; timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/psol -o p --output-format csv -- $CMD > /tmp/psol.log 2>&1 || { tail -5 /tmp/psol.log; exit 1; }
 mkdir -p gpurun_out/$TAG
