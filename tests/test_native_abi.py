@@ -113,3 +113,15 @@ def test_ctypes_structs_match_the_header(tmp_path):
         cls = structs[name]
         assert int(size) == ctypes.sizeof(cls), name
         assert [int(o) for o in offsets] == [getattr(cls, f).offset for f, _ in cls._fields_], name
+
+
+def test_graft_entry_build_checks_the_headers_version():
+    """__graft_entry__.build() compares the library with the version include/ssrs_hip.h declares (it used to carry a literal
+    that two ABI bumps of round 4 left behind: the driver's build check would have failed)."""
+    import os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, '__graft_entry__.py')).read()
+    assert 'SSRS_VERSION' in src and not re.search(r'ssrs_version\(\)\s*==\s*\d', src)
+    from ssrs_amd import _native
+    declared = int(re.search(r'#define\s+SSRS_VERSION\s+(\d+)', open(os.path.join(root, 'include', 'ssrs_hip.h')).read()).group(1))
+    assert _native.lib().ssrs_version() == declared
