@@ -216,3 +216,17 @@ def test_step_case_splits_a_sub_batch_whose_uint32_counts_wrapped():
             sim._step_case(torch.zeros((1000, 2), dtype=torch.int32), 0, (None, None), 30, None, widest_share=1000)
     finally:
         movmodel.simulate_tracks = real
+
+
+def test_bench_cuts_sub_batches_like_the_simulator():
+    """bench.py --hist-safe-tracks defaults to Config.hist_safe_tracks, and both hand sub-batches of more than 100 000 tracks to
+    the library's 64-bit counts (ssrs_tracks_simulate_h64)."""
+    import os, re
+    from ssrs_amd import Config
+    from ssrs_amd.simulator import Simulator
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, 'bench.py')).read()
+    m = re.search(r"--hist-safe-tracks', type=int, default=([\d_]+)", src)
+    assert m and int(m.group(1).replace('_', '')) == Config().hist_safe_tracks
+    m = re.search(r"in_lib = safe > ([\d_]+)", src)
+    assert m and int(m.group(1).replace('_', '')) == Simulator._HIST64_FROM_TRACKS
