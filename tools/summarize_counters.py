@@ -15,7 +15,7 @@ def main(title, dirs):
     for d in dirs:
         for f in glob.glob(f'{d}/**/*counter_collection.csv', recursive=True):
             for r in csv.DictReader(open(f)):
-                name = r['Kernel_Name'].split('(')[0].replace('void ', '')
+                name = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '')
                 c = r['Counter_Name']
                 if c not in counters:
                     counters.append(c)

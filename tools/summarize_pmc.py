@@ -23,7 +23,7 @@ def collect(d, counter):
         for r in csv.DictReader(open(f)):
             if r['Counter_Name'] != counter:
                 continue
-            name = r['Kernel_Name'].split('(')[0].replace('void ', '')
+            name = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '')
             per[name][0] += float(r['Counter_Value'])
             per[name][1] += 1
     return per
